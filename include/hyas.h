@@ -1,0 +1,227 @@
+/*
+ * hyas.h -- C ABI of the MI355X Hybrid A* expansion path.
+ *
+ * Every entry point replaces one piece of the reference planner
+ * (JialiangHan/path_planner); the file:line after "replaces" is the reference
+ * interface it stands in for.  Conventions: extern "C", plain pointers and
+ * sizes, caller-allocated outputs, return 0 on success or a negative
+ * HYAS_E* code, no exceptions cross the boundary, one context per GPU, a
+ * context is not thread-safe, every call is synchronous on the context's
+ * stream.  Pointers are HOST pointers unless the name ends in _dev.
+ */
+#ifndef HYAS_H
+#define HYAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYAS_OK 0
+#define HYAS_EINVAL (-22)   /* bad argument / unsupported parameter */
+#define HYAS_ENOMEM (-12)   /* device or host allocation failed */
+#define HYAS_ENODEV (-19)   /* no usable GPU / HIP error */
+#define HYAS_ESTATE (-1)    /* call order violated (e.g. no costmap yet) */
+#define HYAS_ERANGE (-34)   /* size beyond a documented maximum */
+
+#define HYAS_MODE_POLYGON 0   /* live collision test of the reference */
+#define HYAS_MODE_FOOTPRINT 1 /* per-heading footprint cell lists */
+
+#define HYAS_CURVE_DUBINS 0
+#define HYAS_CURVE_RS 1
+
+#define HYAS_MAX_SUCC 8 /* most successors one node can generate */
+
+/* Planner parameters.  Field names, meaning and defaults follow
+ * ParameterCollisionDetection and ParameterHybridAStar
+ * (include/parameter_manager.h:10-42, :124-175).  hyas_default_params()
+ * fills the struct defaults of the reference; hyas_hot_path_params() the
+ * fixed-step Reeds-Shepp configuration the benchmarks are quoted on. */
+typedef struct hyas_params
+{
+    /* ParameterCollisionDetection */
+    int32_t position_resolution;      /* 10 */
+    int32_t headings;                 /* 72 */
+    float cd_min_turning_radius;      /* 6: radius of the heuristic table */
+    int32_t curve_type;               /* 0 Dubins, 1 Reeds-Shepp */
+    float vehicle_width;              /* 1 */
+    float vehicle_length;             /* 2 */
+    float obstacle_detection_range;   /* 5 */
+    int32_t map_boundary_obstacle;    /* 0 (only 0 is supported) */
+    /* ParameterHybridAStar */
+    int32_t number_of_successors;     /* 3 */
+    int32_t adaptive_steering_angle_and_step_size; /* must be 0 */
+    int32_t adaptive_step_size;       /* must be 0 */
+    int32_t analytical_expansion_every_point;      /* 1 */
+    int32_t analytical_expansion;     /* 1 */
+    float penalty_turning;            /* 1.05 */
+    float penalty_reverse;            /* 1 */
+    float penalty_change_of_direction;/* 2 */
+    int32_t reverse;                  /* 0 */
+    int32_t max_iterations;           /* 10000 */
+    float steering_angle;             /* 5 [deg] */
+    float goal_range;                 /* 1e-3 */
+    float tie_breaker;                /* 0.01 */
+    float min_turning_radius;         /* 6: radius of the analytic shot */
+    /* footprint-lookup mode, Constants:: (include/constants.h:35-58) */
+    double fp_width;                  /* 0.18 */
+    double fp_length;                 /* 0.22 */
+    float fp_cell_size;               /* 1 */
+    int32_t reserved;
+} hyas_params;
+
+/* A search node as the expansion kernels see it: the fields of Node3D
+ * (include/node3d.h:100-124) that CreateSuccessor/UpdateCostSoFar read. */
+typedef struct hyas_node
+{
+    float x, y, t; /* pose, t in [0, 2pi) */
+    float g;       /* cost so far */
+    int32_t prim;  /* motion primitive 0..5 */
+} hyas_node;
+
+typedef struct hyas_goal
+{
+    float x, y, t;
+} hyas_goal;
+
+/* One traversable successor, in the order the reference emits them. */
+typedef struct hyas_succ
+{
+    float x, y, t;
+    float g;       /* UpdateCostSoFar result */
+    float h;       /* UpdateHeuristic result */
+    int32_t idx;   /* Node3D::setIdx */
+    int8_t prim;
+    uint8_t free;  /* always 1 for an emitted successor */
+    uint16_t pad;
+} hyas_succ;
+
+#define HYAS_STATUS_NO_PATH 0   /* open list ran empty */
+#define HYAS_STATUS_GOAL 1      /* goal test passed on a popped node */
+#define HYAS_STATUS_SHOT 2      /* analytic expansion connected */
+#define HYAS_STATUS_MAX_ITER 3  /* max_iterations reached: partial path */
+#define HYAS_STATUS_BAD_POSE 4  /* start or goal rejected (makePlan pre-check) */
+
+typedef struct hyas_result
+{
+    int32_t status;
+    int32_t nodes_explored; /* pops incl. lazily deleted ones */
+    int32_t nodes_expanded; /* nodes closed and expanded */
+    int32_t successors;     /* successors that received a verdict + g + h */
+    int32_t path_len;       /* poses in the final path */
+    float g_final;          /* g of the node the path was closed from */
+    float shot_length;      /* analytic-curve length, 0 if none */
+    float path_length;      /* sum of pose-to-pose distances */
+} hyas_result;
+
+typedef struct hyas_ctx hyas_ctx;
+
+void hyas_default_params(hyas_params *p);
+void hyas_hot_path_params(hyas_params *p);
+
+/* replaces: HybridAStarPlanner ctor + parameter load,
+ * src/hybrid_a_star_planner.cpp:17-35, :59.  device = HIP device ordinal. */
+hyas_ctx *hyas_create(const hyas_params *params, int device);
+void hyas_destroy(hyas_ctx *ctx);
+const char *hyas_last_error(const hyas_ctx *ctx);
+
+/* replaces: HybridAStarPlanner::initialize(name, Costmap2D*, frame)
+ * src/hybrid_a_star_planner.cpp:54-87 = CollisionDetection::UpdateGrid
+ * (src/collisiondetection.cpp:26-54) + LookupTable::Initialize
+ * (src/lookup_table.cpp:20-46).  charmap is costmap_2d's row-major cost
+ * array (0 free .. 254 lethal, 255 unknown).  build_table != 0 also builds
+ * the heuristic table for params.curve_type on this GPU; pass 0 when the
+ * table is installed afterwards with hyas_table_install_dev. */
+int hyas_set_costmap(hyas_ctx *ctx, const uint8_t *charmap, uint32_t w, uint32_t h,
+                     double resolution, double origin_x, double origin_y, int build_table);
+
+/* Footprint-list mode only: a bare occupancy grid of any size with unit
+ * cells and origin 0 (what the table of include/lookup.h assumes); no obstacle
+ * polygons and no heuristic table are built.  No counterpart call in the
+ * reference: its footprint table (include/collisiondetection.h:306) is never
+ * attached to a grid. */
+int hyas_set_grid(hyas_ctx *ctx, const uint8_t *charmap, uint32_t w, uint32_t h);
+
+/* Obstacle polygons of CollisionDetection::SetObstacleVec
+ * (src/collisiondetection.cpp:262-317), 8 floats (4 vertices) each; returns the
+ * polygon count.  hyas_in_range_count: size of in_range_obstacle_map_[key]
+ * (:319-354), 0 for an absent key, -1 for a key outside the grid. */
+int hyas_get_obstacles(const hyas_ctx *ctx, float *out, size_t cap_polygons);
+int hyas_in_range_count(const hyas_ctx *ctx, uint32_t key);
+
+/* replaces: CollisionDetection::IsTraversable(const Node3D&)
+ * src/collisiondetection.cpp:93-127 (mode POLYGON) or the footprint-list
+ * configurationTest the table of include/lookup.h:30-284 was built for
+ * (mode FOOTPRINT).  xyt = n x {x,y,t}; pred_xy = n x {x,y} of the
+ * predecessor or NULL (pose test only); free_out[i] = 1 iff traversable. */
+int hyas_collision_batch(hyas_ctx *ctx, int mode, const float *xyt, const float *pred_xy,
+                         size_t n, uint8_t *free_out);
+int hyas_collision_batch_dev(hyas_ctx *ctx, int mode, const float *xyt_dev,
+                             const float *pred_xy_dev, size_t n, uint8_t *free_out_dev);
+
+/* Footprint table of mode FOOTPRINT as the reference lays it out
+ * (Constants::config, include/constants.h:70-80): entries =
+ * position_resolution^2 * headings, each {int32 length; int32 pos[64][2]}.
+ * Copies min(cap, entries) entries; returns the entry count. */
+int hyas_footprint_table(hyas_ctx *ctx, int32_t *out, size_t cap_entries);
+
+/* replaces: HybridAStar::CreateSuccessor + UpdateCostSoFar + UpdateHeuristic
+ * src/hybrid_a_star.cpp:540-756, :761-811, :316-366 for n independent
+ * (node, goal) pairs.  UpdateCostSoFar compares each successor's primitive
+ * with preds[i].prim.  twod_cost = n x hyas_twod_size() floats, the 2D cost
+ * map of each goal (hyas_flood), or NULL for all-zero.  out = n x
+ * hyas_num_successors() slots, compacted per node; count[i] = emitted. */
+int hyas_expand_batch(hyas_ctx *ctx, const hyas_node *preds, const hyas_goal *goals,
+                      const float *twod_cost, size_t n, hyas_succ *out, uint8_t *count);
+int hyas_num_successors(const hyas_ctx *ctx);
+
+/* replaces: HybridAStar::AnalyticExpansions src/hybrid_a_star.cpp:371-534.
+ * ok[i] = 1 iff every sample of the curve from nodes[i] to goals[i] is
+ * traversable; len[i] = curve length. */
+int hyas_shot_batch(hyas_ctx *ctx, const hyas_node *nodes, const hyas_goal *goals, size_t n,
+                    uint8_t *ok, float *len);
+
+/* replaces: HybridAStar::BuildAStarCostMap src/hybrid_a_star.cpp:1020-1074.
+ * out = hyas_twod_size() floats (w*h + w + 1: Node2D::setIdx can land one row
+ * past the grid), indexed by Node2D::setIdx, -1 where the flood never arrived. */
+int hyas_twod_size(const hyas_ctx *ctx);
+int hyas_flood(hyas_ctx *ctx, const hyas_goal *goal, float *out);
+
+/* replaces: LookupTable::CalculateReedsSheppLookup / CalculateDubinsLookup
+ * src/lookup_table.cpp:147-224, restricted to heading-loop iterations
+ * [slice_begin, slice_end).  out_dev (DEVICE memory) receives
+ * (slice_end-slice_begin) x ny x nx costs in loop order; nx, ny and the
+ * slice count come from hyas_table_dims. */
+int hyas_table_dims(const hyas_ctx *ctx, int32_t *nx, int32_t *ny, int32_t *nslices);
+int hyas_table_build_dev(hyas_ctx *ctx, int curve, int slice_begin, int slice_end,
+                         float *out_dev);
+/* Applies the reference's first-write-wins emplace (src/lookup_table.cpp:176,
+ * :215) of all nslices raw slices into the context's keyed table. */
+int hyas_table_install_dev(hyas_ctx *ctx, int curve, const float *raw_dev);
+/* replaces: LookupTable::Get{ReedsShepp,Dubins}Cost src/lookup_table.cpp:56-96
+ * for n relative poses {|dx|,|dy|,dt}. */
+int hyas_table_lookup(hyas_ctx *ctx, const float *xyt, size_t n, float *cost);
+
+/* replaces: Expander::calculatePath / HybridAStar::calculatePath
+ * src/hybrid_a_star.cpp:982-1018 (GetPath :41-311) for n independent
+ * queries, preceded by the makePlan pose checks
+ * (src/hybrid_a_star_planner.cpp:126-155).  Paths and expansion orders of the
+ * last batch stay in the context until the next call. */
+int hyas_plan_batch(hyas_ctx *ctx, const float *starts_xyt, const float *goals_xyt, size_t n,
+                    hyas_result *out);
+/* Copies min(cap, len) poses {x,y,t} / expanded idx of query i; returns len. */
+int hyas_get_path(const hyas_ctx *ctx, size_t i, float *xyt, size_t cap);
+int hyas_get_expanded(const hyas_ctx *ctx, size_t i, int32_t *idx, size_t cap);
+
+/* Time in milliseconds the GPU spent in each kernel family during the last
+ * hyas_plan_batch / *_batch call, measured with HIP events on the context's
+ * stream.  which: 0 shot, 1 expand, 2 collision, 3 table, 4 flood/other. */
+double hyas_last_kernel_ms(const hyas_ctx *ctx, int which, int64_t *launches);
+void hyas_reset_kernel_timers(hyas_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYAS_H */

@@ -1,0 +1,2179 @@
+/*
+ * oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Serial CPU restatement of the Hybrid A* expansion path of
+ * JialiangHan/path_planner, written to be read side by side with the
+ * reference.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call this file; the product library
+ * (path_planner_amd/csrc) never does.
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * the reference root).  Arithmetic types (float vs double, operand order) are
+ * kept exactly as the C++ usual arithmetic conversions give them in the
+ * reference; elementary functions go through include/hyas_math.h (or glibc
+ * when built with -DORC_USE_LIBM) -- see the note in that header.
+ *
+ * Parity pins: Utility:: known answers of test/test.cpp (tests/golden/
+ * utility_kat.json); Reeds-Shepp known answers and the 60x30 table checksum
+ * recorded from the in-tree src/ReedsShepp.cpp; the Dubins words against
+ * oracle/_ref (src/dubins.cpp compiled as is).  Not pinned by any reference
+ * fixture ("parity unpinned"): collision verdicts, successor sets, g/h,
+ * expansion order (Boost binomial-heap tie order is replaced by
+ * "lowest f, then earliest push"), costmap_2d::worldToMap (restated from its
+ * documented semantics), OMPL's Reeds-Shepp/Dubins distance (the in-tree
+ * ReedsShepp.cpp stands in for it).
+ */
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <queue>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/hyas.h"
+#include "../include/hyas_math.h"
+
+namespace orc
+{
+
+// ---------------------------------------------------------------- math switch
+#ifdef ORC_USE_LIBM
+static inline float m_sinf(float x) { return sinf(x); }
+static inline float m_cosf(float x) { return cosf(x); }
+static inline float m_acosf(float x) { return acosf(x); }
+static inline float m_atan2f(float y, float x) { return atan2f(y, x); }
+static inline double m_sin(double x) { return sin(x); }
+static inline double m_cos(double x) { return cos(x); }
+static inline double m_atan2(double y, double x) { return atan2(y, x); }
+static inline double m_asin(double x) { return asin(x); }
+static inline double m_acos(double x) { return acos(x); }
+static inline double m_fmod(double x, double y) { return fmod(x, y); }
+#else
+static inline float m_sinf(float x) { return hy_sinf(x); }
+static inline float m_cosf(float x) { return hy_cosf(x); }
+static inline float m_acosf(float x) { return hy_acosf(x); }
+static inline float m_atan2f(float y, float x) { return hy_atan2f(y, x); }
+static inline double m_sin(double x) { return hy_sin(x); }
+static inline double m_cos(double x) { return hy_cos(x); }
+static inline double m_atan2(double y, double x) { return hy_atan2(y, x); }
+static inline double m_asin(double x) { return hy_asin(x); }
+static inline double m_acos(double x) { return hy_acos(x); }
+static inline double m_fmod(double x, double y) { return hy_fmod(x, y); }
+#endif
+static inline float m_sqrtf(float x) { return hy_sqrtf(x); }
+static inline float m_fabsf(float x) { return hy_fabsf(x); }
+static inline float m_floorf(float x) { return hy_floorf(x); }
+static inline float m_roundf(float x) { return hy_roundf(x); }
+
+static const double kPi = 3.14159265358979323846; // M_PI
+
+// ------------------------------------------------------------ Eigen stand-ins
+// Eigen::Vector2f semantics used by the reference: component-wise +,-, scalar
+// *, dot = x1*x2 + y1*y2, norm = sqrt(x*x + y*y), normalized() divides by the
+// norm when squaredNorm > 0.
+struct V2
+{
+    float x, y;
+};
+static inline V2 operator-(V2 a, V2 b) { return V2{a.x - b.x, a.y - b.y}; }
+static inline V2 operator+(V2 a, V2 b) { return V2{a.x + b.x, a.y + b.y}; }
+static inline bool operator==(V2 a, V2 b) { return a.x == b.x && a.y == b.y; }
+static inline float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+static inline float norm(V2 a) { return m_sqrtf(a.x * a.x + a.y * a.y); }
+typedef std::vector<V2> Polygon; // 5 vertices, first repeated
+
+// ---------------------------------------------------------------- Utility::
+// src/utility.cpp:1180-1185
+static float ConvertDegToRad(float deg)
+{
+    float rad = (float)((double)(deg / 360 * 2) * kPi);
+    return rad;
+}
+
+// src/utility.cpp:1249-1268
+static float RadToZeroTo2P(float rad)
+{
+    const double two_pi = (double)2.f * kPi;
+    if ((double)rad >= 0 && (double)rad < two_pi)
+        return rad;
+    float out = (float)m_fmod((double)rad, two_pi);
+    if (out < 0)
+        out = (float)((double)out + two_pi);
+    if (hy_fabs((double)out - 2 * kPi) < 1e-3)
+        out = 0;
+    return out;
+}
+
+// src/utility.cpp:1210-1231
+static float RadNormalization(float rad)
+{
+    if ((double)rad >= -kPi && (double)rad <= kPi)
+        return rad;
+    const double two_pi = (double)2.f * kPi;
+    float out = (float)m_fmod((double)rad, two_pi);
+    if (out < 0)
+        out = (float)((double)out + two_pi);
+    if ((double)out > kPi)
+        out = (float)((double)out - (double)2.0f * kPi);
+    if ((double)m_fabsf(out) < 1e-6)
+        out = 0;
+    return out;
+}
+
+// src/utility.cpp:209-249.  Argument order: (p1, p3, p2), p2 is the query.
+static bool OnSegment(V2 p1, V2 p3, V2 p2)
+{
+    if ((double)m_fabsf(p2.x - p1.x) < 1e-3 && (double)m_fabsf(p2.x - p3.x) < 1e-3 &&
+        p2.y <= std::max(p1.y, p3.y) && p2.y >= std::min(p1.y, p3.y))
+        return true;
+    if (p2.x <= std::max(p1.x, p3.x) && p2.x >= std::min(p1.x, p3.x) &&
+        (double)m_fabsf(p2.y - p1.y) < 1e-3 && (double)m_fabsf(p2.y - p3.y) < 1e-3)
+        return true;
+    if (p2.x <= std::max(p1.x, p3.x) && p2.x >= std::min(p1.x, p3.x) &&
+        p2.y <= std::max(p1.y, p3.y) && p2.y >= std::min(p1.y, p3.y))
+    {
+        V2 p1p2 = p2 - p1;
+        V2 p1p3 = p3 - p1;
+        return (double)m_fabsf(dot(p1p2, p1p3) / norm(p1p2) / norm(p1p3) - 1) < 1e-6;
+    }
+    return false;
+}
+
+// src/utility.cpp:251-271
+static bool IsPointOnLine(V2 point, V2 start, V2 unit_vector)
+{
+    V2 diff = point - start;
+    if ((double)m_fabsf(diff.x) < 1e-3 && (double)m_fabsf(diff.y) < 1e-3)
+        return true;
+    float angle = m_acosf(dot(diff, unit_vector) / norm(diff) / norm(unit_vector));
+    if ((double)m_fabsf(angle) < 1e-3 || hy_fabs((double)angle - kPi) < 1e-3)
+        return true;
+    return false;
+}
+
+// src/utility.cpp:273-279
+static float CrossProduct(V2 p1, V2 p2) { return p1.x * p2.y - p2.x * p1.y; }
+
+// src/utility.cpp:280-306
+static int IsIntersect(V2 p1, V2 p2, V2 p3, V2 p4)
+{
+    if ((p1.x == p2.x && p2.x == p3.x && p3.x == p4.x) ||
+        (p1.y == p2.y && p2.y == p3.y && p3.y == p4.y))
+        return 0;
+    if (std::max(p3.x, p4.x) < std::min(p1.x, p2.x) || std::max(p3.y, p4.y) < std::min(p1.y, p2.y) ||
+        std::max(p1.x, p2.x) < std::min(p3.x, p4.x) || std::max(p1.y, p2.y) < std::min(p3.y, p4.y))
+        return 0;
+    if (CrossProduct(p1 - p3, p4 - p3) * CrossProduct(p2 - p3, p4 - p3) <= 0 &&
+        CrossProduct(p3 - p2, p1 - p2) * CrossProduct(p4 - p2, p1 - p2) <= 0)
+        return 1;
+    return 0;
+}
+
+// src/utility.cpp:308-327
+static V2 FindIntersectionPoint(V2 p1, V2 p2, V2 p3, V2 p4)
+{
+    if (0 == IsIntersect(p1, p2, p3, p4))
+        return V2{10000, 10000};
+    V2 dir_1 = p2 - p1, dir_2 = p4 - p3;
+    float t = CrossProduct(p3 - p1, dir_2) / CrossProduct(dir_1, dir_2);
+    return p1 + V2{t * dir_1.x, t * dir_1.y};
+}
+
+// src/utility.cpp:328-374
+static int IsAboveSegment(V2 p1, V2 p2, V2 p3)
+{
+    const int above = 1, on_segment = 1, below = 0;
+    if (OnSegment(p1, p2, p3))
+        return on_segment;
+    if ((p2 - p1).x == 0)
+        return p3.x > p1.x ? below : above;
+    if ((p2 - p1).y == 0)
+        return p3.y > p1.y ? above : below;
+    float k = (p2 - p1).y / (p2 - p1).x;
+    float b = p1.y - k * p1.x;
+    return (k * p3.x + b - p3.y < 0) ? above : below;
+}
+
+// src/utility.cpp:375-422
+static int IsInsidePolygon(const Polygon &polygon, V2 point)
+{
+    V2 far_away_point{10000, point.y};
+    int number_intersection = 0;
+    for (size_t i = 0; i + 1 < polygon.size(); ++i)
+    {
+        if (IsIntersect(point, far_away_point, polygon[i], polygon[i + 1]) == 1)
+        {
+            V2 ip = FindIntersectionPoint(point, far_away_point, polygon[i], polygon[i + 1]);
+            if ((double)norm(polygon[i] - ip) < 1e-3)
+            {
+                if (IsAboveSegment(point, far_away_point, polygon[i + 1]) == 0)
+                    number_intersection += 1;
+            }
+            else if ((double)norm(polygon[i + 1] - ip) < 1e-3)
+            {
+                if (IsAboveSegment(point, far_away_point, polygon[i]) == 0)
+                    number_intersection += 1;
+            }
+            else
+                number_intersection += 1;
+        }
+    }
+    return (number_intersection % 2) == 0 ? 0 : 1;
+}
+
+// src/utility.cpp:430-443
+static bool IsOnPolygon(const Polygon &polygon, V2 point)
+{
+    for (size_t i = 0; i + 1 < polygon.size(); ++i)
+        if (OnSegment(polygon[i], polygon[i + 1], point))
+            return true;
+    return false;
+}
+
+// src/utility.cpp:457-474
+static Polygon CreatePolygon(V2 origin, float width = 1, float height = 1)
+{
+    Polygon p;
+    p.push_back(origin);
+    p.push_back(V2{width + origin.x, origin.y});
+    p.push_back(V2{width + origin.x, origin.y + height});
+    p.push_back(V2{origin.x, origin.y + height});
+    p.push_back(origin);
+    return p;
+}
+
+// src/utility.cpp:476-510.  Matrix2f * Vector2f = (m00*v0 + m01*v1, m10*v0 + m11*v1).
+static Polygon CreatePolygon(V2 center, float width, float height, float heading)
+{
+    V2 pt[4] = {{-width / 2, -height / 2}, {+width / 2, -height / 2}, {+width / 2, +height / 2}, {-width / 2, +height / 2}};
+    float m00 = m_cosf(heading), m01 = -m_sinf(heading), m10 = m_sinf(heading), m11 = m_cosf(heading);
+    Polygon p;
+    for (int i = 0; i < 4; ++i)
+        p.push_back(center + V2{m00 * pt[i].x + m01 * pt[i].y, m10 * pt[i].x + m11 * pt[i].y});
+    p.push_back(p[0]);
+    return p;
+}
+
+// src/utility.cpp:521-526
+static float GetDistanceFromPointToPoint(V2 p1, V2 p2) { return norm(p1 - p2); }
+
+// src/utility.cpp:528-540
+static int IsSegmentIntersectWithPolygon(const Polygon &polygon, V2 start, V2 end)
+{
+    for (size_t i = 0; i + 1 < polygon.size(); ++i)
+        if (IsIntersect(polygon[i], polygon[i + 1], start, end))
+            return 1;
+    return 0;
+}
+
+// src/utility.cpp:1591-1596 (Eigen normalized())
+static V2 GetUnitVector(V2 start, V2 end)
+{
+    V2 diff = end - start;
+    float z = diff.x * diff.x + diff.y * diff.y;
+    if (z > 0)
+    {
+        float n = m_sqrtf(z);
+        return V2{diff.x / n, diff.y / n};
+    }
+    return diff;
+}
+
+// src/utility.cpp:578-592
+static float GetDistanceFromPointToLine(V2 point, V2 start, V2 unit_vector)
+{
+    if (IsPointOnLine(point, start, unit_vector))
+        return 0;
+    float projection_length = m_fabsf(dot(point - start, unit_vector));
+    return m_sqrtf(norm(point - start) * norm(point - start) - projection_length * projection_length);
+}
+
+// src/utility.cpp:541-576
+static float GetDistanceFromSegmentToPoint(V2 start, V2 end, V2 point)
+{
+    if (OnSegment(start, end, point))
+        return 0;
+    V2 far_point, unit_vector = GetUnitVector(start, end);
+    float distance_to_start = GetDistanceFromPointToPoint(start, point);
+    float distance_to_goal = GetDistanceFromPointToPoint(end, point);
+    far_point = distance_to_start > distance_to_goal ? start : end;
+    float projection_length = m_fabsf(dot(point - far_point, end - start)) / norm(end - start);
+    if (projection_length > norm(end - start))
+        return std::min(distance_to_start, distance_to_goal);
+    return GetDistanceFromPointToLine(point, start, unit_vector);
+}
+
+// src/utility.cpp:594-619
+static float GetDistanceFromPolygonToPoint(const Polygon &polygon, V2 point)
+{
+    float min_distance = 100000;
+    if (IsOnPolygon(polygon, point))
+        return 0;
+    if (IsInsidePolygon(polygon, point))
+        return -1;
+    for (size_t i = 0; i + 1 < polygon.size(); ++i)
+    {
+        float d = GetDistanceFromSegmentToPoint(polygon[i], polygon[i + 1], point);
+        if (d < min_distance)
+            min_distance = d;
+    }
+    return min_distance;
+}
+
+// src/utility.cpp:956-966
+static bool IsPolygonIntersectWithPolygon(const Polygon &polygon1, const Polygon &polygon2)
+{
+    for (size_t i = 0; i + 1 < polygon1.size(); ++i)
+        if (IsSegmentIntersectWithPolygon(polygon2, polygon1[i], polygon1[i + 1]))
+            return true;
+    return false;
+}
+
+// src/utility.cpp:967-997
+static float GetDistanceFromPolygonToSegment(const Polygon &polygon, V2 start, V2 end)
+{
+    float out = 100000;
+    if (IsSegmentIntersectWithPolygon(polygon, start, end))
+        return -1;
+    float d = GetDistanceFromPolygonToPoint(polygon, start);
+    if (out > d)
+        out = d;
+    d = GetDistanceFromPolygonToPoint(polygon, end);
+    if (out > d)
+        out = d;
+    for (const V2 &vertex : polygon)
+    {
+        d = GetDistanceFromSegmentToPoint(start, end, vertex);
+        if (out > d)
+            out = d;
+    }
+    return out;
+}
+
+// src/utility.cpp:999-1012
+static bool IsPolygonInNeighbor(const Polygon &a, const Polygon &b)
+{
+    for (const V2 &v1 : a)
+        for (const V2 &v2 : b)
+            if (v1 == v2)
+                return true;
+    return false;
+}
+
+// src/utility.cpp:1014-1058
+static Polygon CombinePolygon(const Polygon &p1, const Polygon &p2)
+{
+    Polygon out;
+    if (!IsPolygonInNeighbor(p1, p2))
+        return out;
+    if (p2[0].y > p1[0].y)
+        out = {p1[0], p1[1], p2[2], p2[3], p1[0]};
+    else if (p2[0].x < p1[0].x)
+        out = {p2[0], p1[1], p1[2], p2[3], p2[0]};
+    else if (p2[0].y < p1[0].y)
+        out = {p2[0], p2[1], p1[2], p1[3], p2[0]};
+    else if (p2[0].x > p1[0].x)
+        out = {p1[0], p2[1], p2[2], p1[3], p1[0]};
+    return out;
+}
+
+// src/utility.cpp:2073-2089
+static std::vector<float> FormSteeringAngleVec(float steering_angle, int number_of_successors)
+{
+    std::vector<float> out;
+    out.push_back(0);
+    if (number_of_successors <= 1)
+        return out;
+    for (int i = 1; i <= (number_of_successors - 1) / 2; i++)
+    {
+        out.push_back(i * ConvertDegToRad(steering_angle));
+        out.push_back(-(i * ConvertDegToRad(steering_angle)));
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ Reeds-Shepp
+// src/ReedsShepp.cpp:45-503.  Segment kinds: 0 none, 1 left, 2 straight, 3 right
+// (include/ReedsShepp.h:50-56).
+static const int kRsType[18][5] = {
+    {1, 3, 1, 0, 0}, {3, 1, 3, 0, 0}, {1, 3, 1, 3, 0}, {3, 1, 3, 1, 0}, {1, 3, 2, 1, 0}, {3, 1, 2, 3, 0},
+    {1, 2, 3, 1, 0}, {3, 2, 1, 3, 0}, {1, 3, 2, 3, 0}, {3, 1, 2, 1, 0}, {3, 2, 3, 1, 0}, {1, 2, 1, 3, 0},
+    {1, 2, 3, 0, 0}, {3, 2, 1, 0, 0}, {1, 2, 1, 0, 0}, {3, 2, 3, 0, 0}, {1, 3, 2, 1, 3}, {3, 1, 2, 3, 1}};
+
+struct RsPath
+{
+    int type = 0;
+    double len[5] = {std::numeric_limits<double>::max(), 0, 0, 0, 0};
+    double total = std::numeric_limits<double>::max();
+    RsPath() {}
+    RsPath(int ty, double t, double u, double v, double w = 0., double x = 0.) : type(ty)
+    {
+        len[0] = t, len[1] = u, len[2] = v, len[3] = w, len[4] = x;
+        total = hy_fabs(t) + hy_fabs(u) + hy_fabs(v) + hy_fabs(w) + hy_fabs(x);
+    }
+};
+
+namespace rs
+{
+static const double pi = kPi, twopi = 2. * kPi;
+static const double ZERO = 10 * std::numeric_limits<double>::epsilon();
+static inline double fabs_(double x) { return hy_fabs(x); }
+
+static inline double mod2pi(double x)
+{
+    double v = m_fmod(x, twopi);
+    if (v < -pi)
+        v += twopi;
+    else if (v > pi)
+        v -= twopi;
+    return v;
+}
+static inline void polar(double x, double y, double &r, double &theta)
+{
+    r = hy_sqrt(x * x + y * y);
+    theta = m_atan2(y, x);
+}
+static inline void tauOmega(double u, double v, double xi, double eta, double phi, double &tau, double &omega)
+{
+    double delta = mod2pi(u - v), A = m_sin(u) - m_sin(delta), B = m_cos(u) - m_cos(delta) - 1.;
+    double t1 = m_atan2(eta * A - xi * B, xi * A + eta * B), t2 = 2. * (m_cos(delta) - m_cos(v) - m_cos(u)) + 3;
+    tau = (t2 < 0) ? mod2pi(t1 + pi) : mod2pi(t1);
+    omega = mod2pi(tau - u + v - phi);
+}
+static inline bool LpSpLp(double x, double y, double phi, double &t, double &u, double &v)
+{
+    polar(x - m_sin(phi), y - 1. + m_cos(phi), u, t);
+    if (t >= -ZERO)
+    {
+        v = mod2pi(phi - t);
+        if (v >= -ZERO)
+            return true;
+    }
+    return false;
+}
+static inline bool LpSpRp(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double t1, u1;
+    polar(x + m_sin(phi), y - 1. - m_cos(phi), u1, t1);
+    u1 = u1 * u1;
+    if (u1 >= 4.)
+    {
+        u = hy_sqrt(u1 - 4.);
+        double theta = m_atan2(2., u);
+        t = mod2pi(t1 + theta);
+        v = mod2pi(t - phi);
+        return t >= -ZERO && v >= -ZERO;
+    }
+    return false;
+}
+static inline bool LpRmL(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double xi = x - m_sin(phi), eta = y - 1. + m_cos(phi), u1, theta;
+    polar(xi, eta, u1, theta);
+    if (u1 <= 4.)
+    {
+        u = -2. * m_asin(.25 * u1);
+        t = mod2pi(theta + .5 * u + pi);
+        v = mod2pi(phi - t + u);
+        return t >= -ZERO && u <= ZERO;
+    }
+    return false;
+}
+static inline bool LpRupLumRm(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double xi = x + m_sin(phi), eta = y - 1. - m_cos(phi), rho = .25 * (2. + hy_sqrt(xi * xi + eta * eta));
+    if (rho <= 1.)
+    {
+        u = m_acos(rho);
+        tauOmega(u, -u, xi, eta, phi, t, v);
+        return t >= -ZERO && v <= ZERO;
+    }
+    return false;
+}
+static inline bool LpRumLumRp(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double xi = x + m_sin(phi), eta = y - 1. - m_cos(phi), rho = (20. - xi * xi - eta * eta) / 16.;
+    if (rho >= 0 && rho <= 1)
+    {
+        u = -m_acos(rho);
+        if (u >= -.5 * pi)
+        {
+            tauOmega(u, u, xi, eta, phi, t, v);
+            return t >= -ZERO && v >= -ZERO;
+        }
+    }
+    return false;
+}
+static inline bool LpRmSmLm(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double xi = x - m_sin(phi), eta = y - 1. + m_cos(phi), rho, theta;
+    polar(xi, eta, rho, theta);
+    if (rho >= 2.)
+    {
+        double r = hy_sqrt(rho * rho - 4.);
+        u = 2. - r;
+        t = mod2pi(theta + m_atan2(r, -2.));
+        v = mod2pi(phi - .5 * pi - t);
+        return t >= -ZERO && u <= ZERO && v <= ZERO;
+    }
+    return false;
+}
+static inline bool LpRmSmRm(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double xi = x + m_sin(phi), eta = y - 1. - m_cos(phi), rho, theta;
+    polar(-eta, xi, rho, theta);
+    if (rho >= 2.)
+    {
+        t = theta;
+        u = 2. - rho;
+        v = mod2pi(t + .5 * pi - phi);
+        return t >= -ZERO && u <= ZERO && v <= ZERO;
+    }
+    return false;
+}
+static inline bool LpRmSLmRp(double x, double y, double phi, double &t, double &u, double &v)
+{
+    double xi = x + m_sin(phi), eta = y - 1. - m_cos(phi), rho, theta;
+    polar(xi, eta, rho, theta);
+    if (rho >= 2.)
+    {
+        u = 4. - hy_sqrt(rho * rho - 4.);
+        if (u <= ZERO)
+        {
+            t = mod2pi(m_atan2((4 - u) * xi - 2 * eta, -2 * xi + (u - 4) * eta));
+            v = mod2pi(t - phi);
+            return t >= -ZERO && v >= -ZERO;
+        }
+    }
+    return false;
+}
+
+typedef bool (*Word)(double, double, double, double &, double &, double &);
+
+// One row of the candidate list: base formula, the (x, y, phi) symmetry
+// (timeflip negates x and phi, reflect negates y and phi), and how (t,u,v) map
+// to the stored segment lengths.
+static void CSC(double x, double y, double phi, RsPath &path)
+{
+    double t, u, v, Lmin = path.total, L;
+    if (LpSpLp(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(14, t, u, v), Lmin = L;
+    if (LpSpLp(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(14, -t, -u, -v), Lmin = L;
+    if (LpSpLp(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(15, t, u, v), Lmin = L;
+    if (LpSpLp(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(15, -t, -u, -v), Lmin = L;
+    if (LpSpRp(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(12, t, u, v), Lmin = L;
+    if (LpSpRp(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(12, -t, -u, -v), Lmin = L;
+    if (LpSpRp(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(13, t, u, v), Lmin = L;
+    if (LpSpRp(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(13, -t, -u, -v);
+}
+static void CCC(double x, double y, double phi, RsPath &path)
+{
+    double t, u, v, Lmin = path.total, L;
+    if (LpRmL(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(0, t, u, v), Lmin = L;
+    if (LpRmL(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(0, -t, -u, -v), Lmin = L;
+    if (LpRmL(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(1, t, u, v), Lmin = L;
+    if (LpRmL(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(1, -t, -u, -v), Lmin = L;
+    double xb = x * m_cos(phi) + y * m_sin(phi), yb = x * m_sin(phi) - y * m_cos(phi);
+    if (LpRmL(xb, yb, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(0, v, u, t), Lmin = L;
+    if (LpRmL(-xb, yb, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(0, -v, -u, -t), Lmin = L;
+    if (LpRmL(xb, -yb, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(1, v, u, t), Lmin = L;
+    if (LpRmL(-xb, -yb, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(1, -v, -u, -t);
+}
+static void CCCC(double x, double y, double phi, RsPath &path)
+{
+    double t, u, v, Lmin = path.total, L;
+    if (LpRupLumRm(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(2, t, u, -u, v), Lmin = L;
+    if (LpRupLumRm(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(2, -t, -u, u, -v), Lmin = L;
+    if (LpRupLumRm(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(3, t, u, -u, v), Lmin = L;
+    if (LpRupLumRm(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(3, -t, -u, u, -v), Lmin = L;
+    if (LpRumLumRp(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(2, t, u, u, v), Lmin = L;
+    if (LpRumLumRp(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(2, -t, -u, -u, -v), Lmin = L;
+    if (LpRumLumRp(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(3, t, u, u, v), Lmin = L;
+    if (LpRumLumRp(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + 2. * fabs_(u) + fabs_(v)))
+        path = RsPath(3, -t, -u, -u, -v);
+}
+static void CCSC(double x, double y, double phi, RsPath &path)
+{
+    double t, u, v, Lmin = path.total - .5 * pi, L;
+    if (LpRmSmLm(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(4, t, -.5 * pi, u, v), Lmin = L;
+    if (LpRmSmLm(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(4, -t, .5 * pi, -u, -v), Lmin = L;
+    if (LpRmSmLm(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(5, t, -.5 * pi, u, v), Lmin = L;
+    if (LpRmSmLm(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(5, -t, .5 * pi, -u, -v), Lmin = L;
+    if (LpRmSmRm(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(8, t, -.5 * pi, u, v), Lmin = L;
+    if (LpRmSmRm(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(8, -t, .5 * pi, -u, -v), Lmin = L;
+    if (LpRmSmRm(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(9, t, -.5 * pi, u, v), Lmin = L;
+    if (LpRmSmRm(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(9, -t, .5 * pi, -u, -v), Lmin = L;
+    double xb = x * m_cos(phi) + y * m_sin(phi), yb = x * m_sin(phi) - y * m_cos(phi);
+    if (LpRmSmLm(xb, yb, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(6, v, u, -.5 * pi, t), Lmin = L;
+    if (LpRmSmLm(-xb, yb, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(6, -v, -u, .5 * pi, -t), Lmin = L;
+    if (LpRmSmLm(xb, -yb, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(7, v, u, -.5 * pi, t), Lmin = L;
+    if (LpRmSmLm(-xb, -yb, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(7, -v, -u, .5 * pi, -t), Lmin = L;
+    if (LpRmSmRm(xb, yb, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(10, v, u, -.5 * pi, t), Lmin = L;
+    if (LpRmSmRm(-xb, yb, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(10, -v, -u, .5 * pi, -t), Lmin = L;
+    if (LpRmSmRm(xb, -yb, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(11, v, u, -.5 * pi, t), Lmin = L;
+    if (LpRmSmRm(-xb, -yb, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(11, -v, -u, .5 * pi, -t);
+}
+static void CCSCC(double x, double y, double phi, RsPath &path)
+{
+    double t, u, v, Lmin = path.total - pi, L;
+    if (LpRmSLmRp(x, y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(16, t, -.5 * pi, u, -.5 * pi, v), Lmin = L;
+    if (LpRmSLmRp(-x, y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(16, -t, .5 * pi, -u, .5 * pi, -v), Lmin = L;
+    if (LpRmSLmRp(x, -y, -phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(17, t, -.5 * pi, u, -.5 * pi, v), Lmin = L;
+    if (LpRmSLmRp(-x, -y, phi, t, u, v) && Lmin > (L = fabs_(t) + fabs_(u) + fabs_(v)))
+        path = RsPath(17, -t, .5 * pi, -u, .5 * pi, -v);
+}
+} // namespace rs
+
+// src/ReedsShepp.cpp:494-503
+static RsPath reedsSheppNormalised(double x, double y, double phi)
+{
+    RsPath path;
+    rs::CSC(x, y, phi, path);
+    rs::CCC(x, y, phi, path);
+    rs::CCCC(x, y, phi, path);
+    rs::CCSC(x, y, phi, path);
+    rs::CCSCC(x, y, phi, path);
+    return path;
+}
+
+// src/ReedsShepp.cpp:544-550
+static RsPath reedsShepp(const double q0[3], const double q1[3], double rho)
+{
+    double dx = q1[0] - q0[0], dy = q1[1] - q0[1], dth = q1[2] - q0[2];
+    double c = m_cos(q0[2]), s = m_sin(q0[2]);
+    double x = c * dx + s * dy, y = -s * dx + c * dy;
+    return reedsSheppNormalised(x / rho, y / rho, dth);
+}
+
+// src/ReedsShepp.cpp:576-625
+static void rsInterpolate(const double q0[3], const RsPath &path, double seg, double rho, double s[3])
+{
+    if (seg < 0.0)
+        seg = 0.0;
+    if (seg > path.total)
+        seg = path.total;
+    double phi, v;
+    s[0] = s[1] = 0.0;
+    s[2] = q0[2];
+    for (unsigned int i = 0; i < 5 && seg > 0; ++i)
+    {
+        if (path.len[i] < 0)
+        {
+            v = std::max(-seg, path.len[i]);
+            seg += v;
+        }
+        else
+        {
+            v = std::min(seg, path.len[i]);
+            seg -= v;
+        }
+        phi = s[2];
+        switch (kRsType[path.type][i])
+        {
+        case 1:
+            s[0] += (m_sin(phi + v) - m_sin(phi));
+            s[1] += (-m_cos(phi + v) + m_cos(phi));
+            s[2] = phi + v;
+            break;
+        case 3:
+            s[0] += (-m_sin(phi - v) + m_sin(phi));
+            s[1] += (m_cos(phi - v) - m_cos(phi));
+            s[2] = phi - v;
+            break;
+        case 2:
+            s[0] += (v * m_cos(phi));
+            s[1] += (v * m_sin(phi));
+            break;
+        default:
+            break;
+        }
+    }
+    s[0] = s[0] * rho + q0[0];
+    s[1] = s[1] * rho + q0[1];
+}
+
+// src/ReedsShepp.cpp:561-574
+static void rsSample(const double q0[3], const double q1[3], double rho, double step_size, double &length,
+                     std::vector<std::array<double, 3>> &points)
+{
+    RsPath path = reedsShepp(q0, q1, rho);
+    length = rho * path.total;
+    for (double seg = 0.0; seg <= length; seg += step_size)
+    {
+        std::array<double, 3> q{};
+        rsInterpolate(q0, path, seg / rho, rho, q.data());
+        points.push_back(q);
+    }
+}
+
+// ----------------------------------------------------------------------- Dubins
+// src/dubins.cpp:81-314, float arithmetic as the reference's <math.h> float
+// overloads give it; mixed double sub-expressions are kept (atan2(-2.0, p),
+// 2*M_PI - acos(..), 6. - d*d ...).
+namespace db
+{
+struct Path
+{
+    float qi[3];
+    float param[3];
+    float rho;
+    int type;
+};
+static const int DIRDATA[6][3] = {{0, 1, 0}, {0, 1, 2}, {2, 1, 0}, {2, 1, 2}, {2, 0, 2}, {0, 2, 0}};
+
+static float fmodr(float x, float y) { return x - y * m_floorf(x / y); }
+static float mod2pi(float theta) { return fmodr(theta, (float)(2 * kPi)); }
+
+struct In
+{
+    float sa, sb, ca, cb, c_ab;
+    In(float alpha, float beta)
+        : sa(m_sinf(alpha)), sb(m_sinf(beta)), ca(m_cosf(alpha)), cb(m_cosf(beta)), c_ab(m_cosf(alpha - beta))
+    {
+    }
+};
+static bool LSL(float alpha, float beta, float d, float *o)
+{
+    In i(alpha, beta);
+    float tmp0 = d + i.sa - i.sb;
+    float p_squared = 2 + (d * d) - (2 * i.c_ab) + (2 * d * (i.sa - i.sb));
+    if (p_squared < 0)
+        return false;
+    float tmp1 = m_atan2f((i.cb - i.ca), tmp0);
+    o[0] = mod2pi(-alpha + tmp1);
+    o[1] = m_sqrtf(p_squared);
+    o[2] = mod2pi(beta - tmp1);
+    return true;
+}
+static bool RSR(float alpha, float beta, float d, float *o)
+{
+    In i(alpha, beta);
+    float tmp0 = d - i.sa + i.sb;
+    float p_squared = 2 + (d * d) - (2 * i.c_ab) + (2 * d * (i.sb - i.sa));
+    if (p_squared < 0)
+        return false;
+    float tmp1 = m_atan2f((i.ca - i.cb), tmp0);
+    o[0] = mod2pi(alpha - tmp1);
+    o[1] = m_sqrtf(p_squared);
+    o[2] = mod2pi(-beta + tmp1);
+    return true;
+}
+static bool LSR(float alpha, float beta, float d, float *o)
+{
+    In i(alpha, beta);
+    float p_squared = -2 + (d * d) + (2 * i.c_ab) + (2 * d * (i.sa + i.sb));
+    if (p_squared < 0)
+        return false;
+    float p = m_sqrtf(p_squared);
+    float tmp2 = (float)((double)m_atan2f((-i.ca - i.cb), (d + i.sa + i.sb)) - m_atan2(-2.0, (double)p));
+    o[0] = mod2pi(-alpha + tmp2);
+    o[1] = p;
+    o[2] = mod2pi(-mod2pi(beta) + tmp2);
+    return true;
+}
+static bool RSL(float alpha, float beta, float d, float *o)
+{
+    In i(alpha, beta);
+    float p_squared = (d * d) - 2 + (2 * i.c_ab) - (2 * d * (i.sa + i.sb));
+    if (p_squared < 0)
+        return false;
+    float p = m_sqrtf(p_squared);
+    float tmp2 = (float)((double)m_atan2f((i.ca + i.cb), (d - i.sa - i.sb)) - m_atan2(2.0, (double)p));
+    o[0] = mod2pi(alpha - tmp2);
+    o[1] = p;
+    o[2] = mod2pi(beta - tmp2);
+    return true;
+}
+static bool RLR(float alpha, float beta, float d, float *o)
+{
+    In i(alpha, beta);
+    float tmp_rlr = (float)((6. - (double)(d * d) + (double)(2 * i.c_ab) + (double)(2 * d * (i.sa - i.sb))) / 8.);
+    if (hy_fabs((double)tmp_rlr) > 1)
+        return false;
+    float p = mod2pi((float)(2 * kPi - (double)m_acosf(tmp_rlr)));
+    float t = mod2pi(alpha - m_atan2f(i.ca - i.cb, d - i.sa + i.sb) + mod2pi((float)((double)p / 2.)));
+    float q = mod2pi(alpha - beta - t + mod2pi(p));
+    o[0] = t, o[1] = p, o[2] = q;
+    return true;
+}
+static bool LRL(float alpha, float beta, float d, float *o)
+{
+    In i(alpha, beta);
+    float tmp_lrl = (float)((6. - (double)(d * d) + (double)(2 * i.c_ab) + (double)(2 * d * (-i.sa + i.sb))) / 8.);
+    if (hy_fabs((double)tmp_lrl) > 1)
+        return false;
+    float p = mod2pi((float)(2 * kPi - (double)m_acosf(tmp_lrl)));
+    float t = mod2pi((float)((double)(-alpha - m_atan2f(i.ca - i.cb, d + i.sa - i.sb)) + (double)p / 2.));
+    float q = mod2pi(mod2pi(beta) - alpha - t + mod2pi(p));
+    o[0] = t, o[1] = p, o[2] = q;
+    return true;
+}
+typedef bool (*Word)(float, float, float, float *);
+static const Word words[6] = {LSL, LSR, RSL, RSR, RLR, LRL};
+
+// src/dubins.cpp:91-140; returns 0 on success
+static int init(const float q0[3], const float q1[3], float rho, Path *path)
+{
+    float dx = q1[0] - q0[0];
+    float dy = q1[1] - q0[1];
+    float D = m_sqrtf(dx * dx + dy * dy);
+    float d = D / rho;
+    if (rho <= 0.)
+        return 3;
+    float theta = mod2pi(m_atan2f(dy, dx));
+    float alpha = mod2pi(q0[2] - theta);
+    float beta = mod2pi(q1[2] - theta);
+    for (int i = 0; i < 3; i++)
+        path->qi[i] = q0[i];
+    path->rho = rho;
+    float best_cost = INFINITY;
+    int best_word = -1;
+    for (int i = 0; i < 6; i++)
+    {
+        float params[3];
+        if (words[i](alpha, beta, d, params))
+        {
+            float cost = params[0] + params[1] + params[2];
+            if (cost < best_cost)
+            {
+                best_word = i;
+                best_cost = cost;
+                path->param[0] = params[0];
+                path->param[1] = params[1];
+                path->param[2] = params[2];
+                path->type = i;
+            }
+        }
+    }
+    if (best_word == -1)
+        return 4;
+    path->type = best_word;
+    return 0;
+}
+static float length(const Path *path)
+{
+    float length = 0.;
+    length += path->param[0];
+    length += path->param[1];
+    length += path->param[2];
+    length = length * path->rho;
+    return length;
+}
+static void segment(float t, const float qi[3], float qt[3], int type)
+{
+    if (type == 0)
+    {
+        qt[0] = qi[0] + m_sinf(qi[2] + t) - m_sinf(qi[2]);
+        qt[1] = qi[1] - m_cosf(qi[2] + t) + m_cosf(qi[2]);
+        qt[2] = qi[2] + t;
+    }
+    else if (type == 2)
+    {
+        qt[0] = qi[0] - m_sinf(qi[2] - t) + m_sinf(qi[2]);
+        qt[1] = qi[1] + m_cosf(qi[2] - t) - m_cosf(qi[2]);
+        qt[2] = qi[2] - t;
+    }
+    else
+    {
+        qt[0] = qi[0] + m_cosf(qi[2]) * t;
+        qt[1] = qi[1] + m_sinf(qi[2]) * t;
+        qt[2] = qi[2];
+    }
+}
+static int sample(const Path *path, float t, float q[3])
+{
+    if (t < 0 || t >= length(path))
+        return 2;
+    float tprime = t / path->rho;
+    float qi[3] = {0, 0, path->qi[2]};
+    const int *types = DIRDATA[path->type];
+    float p1 = path->param[0];
+    float p2 = path->param[1];
+    float q1[3], q2[3];
+    segment(p1, qi, q1, types[0]);
+    segment(p2, q1, q2, types[1]);
+    if (tprime < p1)
+        segment(tprime, qi, q, types[0]);
+    else if (tprime < (p1 + p2))
+        segment(tprime - p1, q1, q, types[1]);
+    else
+        segment(tprime - p1 - p2, q2, q, types[2]);
+    q[0] = q[0] * path->rho + path->qi[0];
+    q[1] = q[1] * path->rho + path->qi[1];
+    q[2] = mod2pi(q[2]);
+    return 0;
+}
+} // namespace db
+
+// ------------------------------------------------------------ costmap_2d facts
+// costmap_2d::Costmap2D is a ROS dependency absent from the reference tree;
+// restated: worldToMap rejects wx<origin or wy<origin, truncates
+// (w-origin)/resolution to int, accepts iff mx<size_x && my<size_y.
+struct Costmap
+{
+    uint32_t w = 0, h = 0;
+    double res = 1, ox = 0, oy = 0;
+    std::vector<uint8_t> cost;
+    bool worldToMap(double wx, double wy, unsigned int &mx, unsigned int &my) const
+    {
+        if (wx < ox || wy < oy)
+            return false;
+        mx = (int)((wx - ox) / res);
+        my = (int)((wy - oy) / res);
+        return mx < w && my < h;
+    }
+};
+
+struct Node3D
+{
+    float x = 0, y = 0, t = 0, g = 999, h = 0;
+    int idx = -1;
+    bool o = false, c = false, reverse = false;
+    int prim = 0;
+    int pred = -1; // index into the query's node arena (shared_ptr in the reference)
+};
+
+// include/node3d.h:65-72
+static int setIdx3D(const Node3D &n, int width, int height, float delta_heading_in_rad, float resolution,
+                    float origin_x, float origin_y)
+{
+    return (int)(m_floorf(m_roundf(n.t / delta_heading_in_rad * 1000) / 1000) * width * height +
+                 m_floorf(m_roundf(((n.y - origin_y) / resolution) * 1000) / 1000) * width +
+                 m_floorf(m_roundf(((n.x - origin_x) / resolution) * 1000) / 1000));
+}
+// include/node2d.h:59-66
+static int setIdx2D(float x, float y, int width, float resolution, float origin_x, float origin_y)
+{
+    return (int)(m_floorf(m_roundf(((y - origin_y) / resolution) * 1000) / 1000) * width +
+                 m_floorf(m_roundf(((x - origin_x) / resolution) * 1000) / 1000));
+}
+
+// Footprint table entry, include/constants.h:62-80
+struct FpConfig
+{
+    int32_t length;
+    int32_t pos[64][2];
+};
+
+struct Ctx
+{
+    hyas_params P;
+    Costmap cm;
+    // CollisionDetection members (include/collisiondetection.h:299-349)
+    float resolution_ = 1, origin_x_ = 0, origin_y_ = 0;
+    std::vector<int8_t> grid;              // nav_msgs::OccupancyGrid data
+    std::vector<Polygon> obstacle_vec_;
+    std::unordered_map<uint32_t, std::vector<Polygon>> in_range_obstacle_map_;
+    // LookupTable: keyed dense store; NaN = key never emplaced
+    std::vector<float> table;
+    int table_curve = -1;
+    // Mode F
+    std::vector<FpConfig> fp;
+    int fp_bb = 0;
+    // last plan
+    std::vector<float> last_path;
+    std::vector<int32_t> last_expanded;
+    bool linear_duplicate_check = true;
+
+    // ------------------------------------------------------- map ingest
+    // src/utility.cpp:166-206
+    void translateCostmap()
+    {
+        int8_t tab[256];
+        tab[0] = 0, tab[253] = 99, tab[254] = 100, tab[255] = -1;
+        for (int i = 1; i < 253; i++)
+            tab[i] = (int8_t)(1 + (97 * (i - 1)) / 251);
+        grid.resize((size_t)cm.w * cm.h);
+        for (size_t i = 0; i < grid.size(); ++i)
+            grid[i] = tab[cm.cost[i]];
+    }
+    // src/collisiondetection.cpp:362-369
+    uint32_t GetNode3DIndexOnGridMap(float x, float y) const
+    {
+        return (uint32_t)(m_floorf(m_roundf(((y - origin_y_) / resolution_) * 1000) / 1000) * cm.w +
+                          m_floorf(m_roundf(((x - origin_x_) / resolution_) * 1000) / 1000));
+    }
+    // src/collisiondetection.cpp:262-317
+    void SetObstacleVec()
+    {
+        obstacle_vec_.clear();
+        float x_limit = origin_x_ + cm.w * resolution_;
+        float y_limit = origin_y_ + cm.h * resolution_;
+        for (float x = origin_x_; x < x_limit;)
+        {
+            for (float y = origin_y_; y < y_limit;)
+            {
+                uint32_t gi = GetNode3DIndexOnGridMap(x, y);
+                if (gi < grid.size() && grid[gi])
+                {
+                    Polygon cur = CreatePolygon(V2{x, y}, resolution_, resolution_);
+                    if (!obstacle_vec_.empty() && IsPolygonInNeighbor(obstacle_vec_.back(), cur))
+                    {
+                        Polygon combined = CombinePolygon(cur, obstacle_vec_.back());
+                        obstacle_vec_.pop_back();
+                        obstacle_vec_.push_back(combined);
+                    }
+                    else
+                        obstacle_vec_.push_back(cur);
+                }
+                y = y + resolution_;
+            }
+            x = x + resolution_;
+        }
+    }
+    // src/collisiondetection.cpp:319-354
+    void SetInRangeObstacle()
+    {
+        in_range_obstacle_map_.clear();
+        float x_limit = origin_x_ + cm.w * resolution_;
+        float y_limit = origin_y_ + cm.h * resolution_;
+        std::vector<Polygon> v;
+        for (float x = origin_x_; x < x_limit;)
+        {
+            for (float y = origin_y_; y < y_limit;)
+            {
+                uint32_t idx = GetNode3DIndexOnGridMap(x, y);
+                v.clear();
+                for (const Polygon &poly : obstacle_vec_)
+                {
+                    float distance = GetDistanceFromPolygonToPoint(poly, V2{x, y});
+                    if (distance < P.obstacle_detection_range)
+                        v.push_back(poly);
+                }
+                in_range_obstacle_map_.emplace(idx, v);
+                y = y + resolution_;
+            }
+            x = x + resolution_;
+        }
+    }
+
+    // ----------------------------------------------- collision (mode POLYGON)
+    // src/collisiondetection.cpp:178-188
+    bool IsOnGrid(float x, float y) const
+    {
+        unsigned int mx, my;
+        return cm.worldToMap(x, y, mx, my);
+    }
+    // src/collisiondetection.cpp:573-606
+    bool CollisionCheckPolygon(const Polygon &polygon)
+    {
+        for (const V2 &pt : polygon)
+            if (!IsOnGrid(pt.x, pt.y))
+                return false;
+        uint32_t key = GetNode3DIndexOnGridMap(polygon[0].x, polygon[0].y);
+        auto it = in_range_obstacle_map_.find(key);
+        if (it != in_range_obstacle_map_.end())
+            for (const Polygon &obst : it->second)
+                if (IsPolygonIntersectWithPolygon(polygon, obst))
+                    return false;
+        return true;
+    }
+    // src/collisiondetection.cpp:608-656
+    bool CollisionCheckSegment(V2 start, V2 end)
+    {
+        if (!IsOnGrid(start.x, start.y) || !IsOnGrid(end.x, end.y))
+            return false;
+        uint32_t ks = GetNode3DIndexOnGridMap(start.x, start.y);
+        uint32_t ke = GetNode3DIndexOnGridMap(end.x, end.y);
+        auto it = in_range_obstacle_map_.find(ks);
+        if (it != in_range_obstacle_map_.end())
+            for (const Polygon &obst : it->second)
+                if ((double)GetDistanceFromPolygonToSegment(obst, start, end) <= 0.5 * (double)P.vehicle_width)
+                    return false;
+        it = in_range_obstacle_map_.find(ke);
+        if (it != in_range_obstacle_map_.end())
+            for (const Polygon &obst : it->second)
+                if ((double)GetDistanceFromPolygonToSegment(obst, start, end) <= 0.5 * (double)P.vehicle_width)
+                    return false;
+        return true;
+    }
+    // src/collisiondetection.cpp:189-214
+    bool configurationTest(float x, float y, float t)
+    {
+        unsigned int sx, sy;
+        if (!cm.worldToMap(x, y, sx, sy))
+            return false;
+        if (cm.cost[sx + sy * cm.w] >= 250)
+            return false;
+        Polygon polygon = CreatePolygon(V2{x, y}, P.vehicle_length, P.vehicle_width, t);
+        return CollisionCheckPolygon(polygon);
+    }
+    // src/collisiondetection.cpp:93-127; has_pred=false is the pred==nullptr arm
+    bool IsTraversable(float x, float y, float t, bool has_pred, float px, float py)
+    {
+        if (!IsOnGrid(x, y))
+            return false;
+        if (has_pred)
+            return configurationTest(x, y, t) && CollisionCheckSegment(V2{x, y}, V2{px, py});
+        return configurationTest(x, y, t);
+    }
+
+    // --------------------------------------------- collision (mode FOOTPRINT)
+    // include/lookup.h:30-284 with Constants:: taken from the params.
+    void buildFootprintTable()
+    {
+        const float cSize = P.fp_cell_size;
+        const double width = P.fp_width, length = P.fp_length;
+        const int size = (int)std::ceil((std::sqrt(width * width + length * length) + 4) / cSize);
+        const int positionResolution = P.position_resolution;
+        const int positions = positionResolution * positionResolution;
+        const int headings = P.headings;
+        const float deltaHeadingRad = (float)(2 * kPi / (double)(float)headings);
+        fp_bb = size;
+        fp_hcross1 = fp_hcross2 = 0;
+        fp.assign((size_t)positions * headings, FpConfig{});
+        struct pt
+        {
+            float x, y;
+        };
+        std::vector<pt> points(positions);
+        for (int i = 0; i < positionResolution; ++i)
+            for (int j = 0; j < positionResolution; ++j)
+            {
+                points[positionResolution * i + j].x = 1.f / positionResolution * j;
+                points[positionResolution * i + j].y = 1.f / positionResolution * i;
+            }
+        std::vector<char> cSpace((size_t)size * size);
+        auto sign = [](float v) { return v >= 0 ? 1 : -1; };
+        for (int q = 0; q < positions; ++q)
+        {
+            float theta = 0;
+            pt c, p[4], nP[4];
+            c.x = (float)size / 2 + points[q].x;
+            c.y = (float)size / 2 + points[q].y;
+            p[0].x = (float)((double)c.x - length / 2 / (double)cSize);
+            p[0].y = (float)((double)c.y - width / 2 / (double)cSize);
+            p[1].x = (float)((double)c.x - length / 2 / (double)cSize);
+            p[1].y = (float)((double)c.y + width / 2 / (double)cSize);
+            p[2].x = (float)((double)c.x + length / 2 / (double)cSize);
+            p[2].y = (float)((double)c.y + width / 2 / (double)cSize);
+            p[3].x = (float)((double)c.x + length / 2 / (double)cSize);
+            p[3].y = (float)((double)c.y - width / 2 / (double)cSize);
+            for (int o = 0; o < headings; ++o)
+            {
+                std::fill(cSpace.begin(), cSpace.end(), 0);
+                for (int j = 0; j < 4; ++j)
+                {
+                    pt temp{p[j].x - c.x, p[j].y - c.y};
+                    nP[j].x = temp.x * m_cosf(theta) - temp.y * m_sinf(theta) + c.x;
+                    nP[j].y = temp.x * m_sinf(theta) + temp.y * m_cosf(theta) + c.y;
+                }
+                theta += deltaHeadingRad;
+                for (int k = 0; k < 4; ++k)
+                {
+                    pt start = nP[k], end = (k < 3) ? nP[k + 1] : nP[0];
+                    int X = (int)start.x, Y = (int)start.y;
+                    cSpace[Y * size + X] = 1;
+                    pt t{end.x - start.x, end.y - start.y};
+                    int stepX = sign(t.x), stepY = sign(t.y);
+                    float tDeltaX = (t.x != 0) ? 1.f / m_fabsf(t.x) : 1000;
+                    float tDeltaY = (t.y != 0) ? 1.f / m_fabsf(t.y) : 1000;
+                    float tMaxX = (stepX > 0) ? tDeltaX * (1 - (start.x - (long)start.x)) : tDeltaX * (start.x - (long)start.x);
+                    float tMaxY = (stepY > 0) ? tDeltaY * (1 - (start.y - (long)start.y)) : tDeltaY * (start.y - (long)start.y);
+                    while ((int)end.x != X || (int)end.y != Y)
+                    {
+                        if (tMaxX < tMaxY && std::abs(X + stepX - (int)end.x) < std::abs(X - (int)end.x))
+                        {
+                            tMaxX = tMaxX + tDeltaX;
+                            X = X + stepX;
+                            cSpace[Y * size + X] = 1;
+                        }
+                        else if (tMaxY < tMaxX && std::abs(Y + stepY - (int)end.y) < std::abs(Y - (int)end.y))
+                        {
+                            tMaxY = tMaxY + tDeltaY;
+                            Y = Y + stepY;
+                            cSpace[Y * size + X] = 1;
+                        }
+                        else if (2 >= std::abs(X - (int)end.x) + std::abs(Y - (int)end.y))
+                        {
+                            if (std::abs(X - (int)end.x) > std::abs(Y - (int)end.y))
+                                X = X + stepX;
+                            else
+                                Y = Y + stepY;
+                            cSpace[Y * size + X] = 1;
+                        }
+                        else
+                            break;
+                    }
+                }
+                fillShape(cSpace, size);
+                int count = 0;
+                FpConfig &e = fp[(size_t)q * headings + o];
+                for (int i = 0; i < size; ++i)
+                    for (int j = 0; j < size; ++j)
+                        if (cSpace[i * size + j])
+                        {
+                            if (count < 64)
+                            {
+                                e.pos[count][0] = j - (int)c.x;
+                                e.pos[count][1] = i - (int)c.y;
+                            }
+                            count++;
+                        }
+                e.length = count;
+            }
+        }
+    }
+    // include/lookup.h:216-240.  hcross1/hcross2 persist across rows and
+    // across table entries in the reference (function-scope variables).
+    int fp_hcross1 = 0, fp_hcross2 = 0;
+    void fillShape(std::vector<char> &cSpace, int size)
+    {
+        for (int i = 0; i < size; ++i)
+        {
+            bool inside = false;
+            for (int j = 0; j < size; ++j)
+            {
+                for (int k = 0; k < size; ++k)
+                {
+                    if (cSpace[i * size + k] && !inside)
+                    {
+                        fp_hcross1 = k;
+                        inside = true;
+                    }
+                    if (cSpace[i * size + k] && inside)
+                        fp_hcross2 = k;
+                }
+                if (j > fp_hcross1 && j < fp_hcross2 && inside)
+                    cSpace[i * size + j] = 1;
+            }
+        }
+    }
+    // Footprint-list pose test.  The reference tree keeps only the table
+    // (include/collisiondetection.h:306); the test loop is the one the table
+    // was designed for: X=(int)x, Y=(int)y, sub-cell (int)((x-X)*pr),
+    // heading bin (int)(t/delta); every listed cell must be on the grid and
+    // below the lethal threshold used by configurationTest (>= 250 collides).
+    bool footprintTest(float x, float y, float t) const
+    {
+        const int pr = P.position_resolution;
+        const float delta = (float)(2 * kPi / (double)(float)P.headings);
+        int X = (int)x, Y = (int)y;
+        int iX = (int)((x - (long)x) * pr);
+        iX = iX > 0 ? iX : 0;
+        int iY = (int)((y - (long)y) * pr);
+        iY = iY > 0 ? iY : 0;
+        int iT = (int)(t / delta);
+        if (iT < 0 || iT >= P.headings || iX >= pr || iY >= pr)
+            return false;
+        int idx = iY * pr * P.headings + iX * P.headings + iT;
+        const FpConfig &e = fp[idx];
+        int n = e.length < 64 ? e.length : 64;
+        for (int i = 0; i < n; ++i)
+        {
+            int cX = X + e.pos[i][0], cY = Y + e.pos[i][1];
+            if (cX < 0 || (uint32_t)cX >= cm.w || cY < 0 || (uint32_t)cY >= cm.h)
+                return false;
+            if (cm.cost[(size_t)cY * cm.w + cX] >= 250)
+                return false;
+        }
+        return true;
+    }
+
+    // ------------------------------------------------------------ LookupTable
+    // src/lookup_table.cpp:123-146
+    int CalculateNode3DIndex(float x, float y, float theta) const
+    {
+        const float delta_heading_in_rad = (float)(2 * kPi / (double)(float)P.headings);
+        float angle = ((double)m_fabsf(theta) < 1e-4) ? 0 : theta;
+        int x_index = (int)(x * P.position_resolution);
+        int y_index = (int)(y * P.position_resolution);
+        return (int)(angle / delta_heading_in_rad) * (int)cm.w * (int)cm.h * P.position_resolution * P.position_resolution +
+               (int)(y_index * P.position_resolution) * (int)cm.w + (int)(x_index);
+    }
+    double curveDistance(int curve, float x, float y, float theta) const
+    {
+        // OMPL's {ReedsShepp,Dubins}StateSpace::distance (double state
+        // (x, y, yaw) from float loop variables), src/lookup_table.cpp:172-174,
+        // :212-214.  Reeds-Shepp: the in-tree ReedsShepp.cpp algorithm.
+        // Dubins: OMPL is absent; the in-tree Walker solver (float) stands in.
+        if (curve == HYAS_CURVE_RS)
+        {
+            double q0[3] = {0, 0, 0}, q1[3] = {x, y, theta};
+            return (double)P.cd_min_turning_radius * reedsShepp(q0, q1, (double)P.cd_min_turning_radius).total;
+        }
+        float q0[3] = {0, 0, 0}, q1[3] = {x, y, theta};
+        db::Path p;
+        if (db::init(q0, q1, P.cd_min_turning_radius, &p) != 0)
+            return 1000000;
+        return db::length(&p);
+    }
+    // The float accumulators of src/lookup_table.cpp:158-183 / :197-222.
+    void tableAxes(std::vector<float> &xs, std::vector<float> &ys, std::vector<float> &ts) const
+    {
+        const float delta_heading_in_rad = (float)(2 * kPi / (double)(float)P.headings);
+        for (float x = 0; x < (float)(int)cm.w; x += 1.0f / P.position_resolution)
+            xs.push_back(x);
+        for (float y = 0; y < (float)(int)cm.h; y += 1.0f / P.position_resolution)
+            ys.push_back(y);
+        for (float th = 0; (double)th < 2 * kPi; th += delta_heading_in_rad)
+            ts.push_back(th);
+    }
+    size_t tableSize() const
+    {
+        return (size_t)(P.headings + 1) * cm.w * cm.h * P.position_resolution * P.position_resolution + (size_t)cm.w * P.position_resolution;
+    }
+    // src/lookup_table.cpp:147-224 (x outer, y, theta inner; first emplace wins;
+    // the x==0 && y==0 column is skipped).  Rows are solved on several threads
+    // and merged in loop order, which keeps first-write-wins intact.
+    void buildTable(int curve, int nthreads)
+    {
+        std::vector<float> xs, ys, ts;
+        tableAxes(xs, ys, ts);
+        const float nanv = std::numeric_limits<float>::quiet_NaN();
+        table.assign(tableSize(), nanv);
+        std::vector<float> raw(xs.size() * ys.size() * ts.size());
+        auto work = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i)
+                for (size_t j = 0; j < ys.size(); ++j)
+                    for (size_t k = 0; k < ts.size(); ++k)
+                        raw[(i * ys.size() + j) * ts.size() + k] = (float)curveDistance(curve, xs[i], ys[j], ts[k]);
+        };
+        std::vector<std::thread> th;
+        if (nthreads < 1)
+            nthreads = 1;
+        size_t per = (xs.size() + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t)
+        {
+            size_t a = t * per, b = std::min(xs.size(), a + per);
+            if (a < b)
+                th.emplace_back(work, a, b);
+        }
+        for (auto &t : th)
+            t.join();
+        for (size_t i = 0; i < xs.size(); ++i)
+            for (size_t j = 0; j < ys.size(); ++j)
+            {
+                if (xs[i] == 0 && ys[j] == 0)
+                    continue;
+                for (size_t k = 0; k < ts.size(); ++k)
+                {
+                    int index = CalculateNode3DIndex(xs[i], ys[j], ts[k]);
+                    if (index >= 0 && (size_t)index < table.size() && table[index] != table[index])
+                        table[index] = raw[(i * ys.size() + j) * ts.size() + k];
+                }
+            }
+        table_curve = curve;
+    }
+    // src/lookup_table.cpp:56-96 (+ :113-122)
+    float tableCost(float x, float y, float t) const
+    {
+        float miss = (table_curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
+        int index = CalculateNode3DIndex(x, y, RadToZeroTo2P(t));
+        if (index >= 0 && (size_t)index < table.size() && table[index] == table[index])
+            return table[index];
+        return miss;
+    }
+
+    size_t twodSize() const { return (size_t)cm.w * cm.h + cm.w + 1; }
+    // ------------------------------------------------------ 2D cost-to-goal
+    // src/hybrid_a_star.cpp:1020-1074 with AStar::CreateSuccessor(pred, 8)
+    // (src/a_star.cpp:214-277, step = resolution_ :340-346) and
+    // AStar::UpdateCostSoFar (:281-288).
+    struct N2
+    {
+        float x, y, g;
+        bool has_pred;
+        float px, py;
+    };
+    struct PqCmp // include/hybrid_a_star.h:45-53
+    {
+        bool operator()(const std::pair<int, double> &l, const std::pair<int, double> &r) const { return l.second >= r.second; }
+    };
+    void buildAStarCostMap(float gx, float gy, std::vector<float> &cost_map /* -1 = absent */)
+    {
+        const int W = cm.w;
+        const int NC = (int)twodSize(); // unordered_map in the reference: any key fits
+        cost_map.assign((size_t)NC, -1.f);
+        std::unordered_map<int, N2> open_set;
+        std::priority_queue<std::pair<int, double>, std::vector<std::pair<int, double>>, PqCmp> open_pq;
+        N2 goal{gx, gy, 0, false, 0, 0};
+        int gid = setIdx2D(gx, gy, W, resolution_, origin_x_, origin_y_);
+        if (gid < 0 || gid >= NC)
+            return;
+        open_set.emplace(gid, goal);
+        open_pq.emplace(gid, (double)goal.g);
+        const float step = resolution_;
+        const float delta[3] = {-step, 0, step};
+        while (!open_pq.empty())
+        {
+            int id = open_pq.top().first;
+            open_pq.pop();
+            N2 &cur = open_set[id];
+            if (cur.has_pred)
+                cur.g = cur.g + norm(V2{cur.x, cur.y} - V2{cur.px, cur.py});
+            int cid = setIdx2D(cur.x, cur.y, W, resolution_, origin_x_, origin_y_);
+            if (cid >= 0 && cid < NC && cost_map[cid] < 0)
+                cost_map[cid] = cur.g;
+            const N2 c = cur; // successors copy the updated node
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                {
+                    if (delta[i] == 0 && delta[j] == 0)
+                        continue;
+                    float xs = c.x + delta[i], ys = c.y + delta[j];
+                    if (!IsOnGrid(xs, ys))
+                        continue;
+                    int nid = setIdx2D(xs, ys, W, resolution_, origin_x_, origin_y_);
+                    if (nid < 0 || nid >= NC)
+                        continue;
+                    if (cost_map[nid] >= 0)
+                        continue;
+                    auto it = open_set.find(nid);
+                    if (it != open_set.end())
+                    {
+                        if (it->second.g > c.g)
+                        {
+                            it->second.g = c.g;
+                            it->second.has_pred = true;
+                            it->second.px = c.x;
+                            it->second.py = c.y;
+                        }
+                    }
+                    else
+                    {
+                        open_set.emplace(nid, N2{xs, ys, c.g, true, c.x, c.y});
+                        open_pq.emplace(nid, (double)c.g);
+                    }
+                }
+        }
+    }
+
+    // ------------------------------------------------------------ HybridAStar
+    float GetDistance(const Node3D &a, const Node3D &b) const { return norm(V2{a.x, a.y} - V2{b.x, b.y}); }
+    float headingDelta() const { return (float)((double)(float)2 * kPi / P.headings); }
+
+    // src/hybrid_a_star.cpp:316-366
+    float heuristic(const Node3D &n, const Node3D &goal, const std::vector<float> &twod) const
+    {
+        float gx = m_fabsf(goal.x - n.x), gy = m_fabsf(goal.y - n.y);
+        float gt = RadToZeroTo2P(goal.t - n.t);
+        float curve_cost = tableCost(gx, gy, gt);
+        float twoD = 0;
+        int id = setIdx2D(n.x, n.y, cm.w, resolution_, origin_x_, origin_y_);
+        if (!twod.empty() && id >= 0 && (size_t)id < twod.size() && twod[id] >= 0)
+            twoD = twod[id];
+        return std::max(curve_cost, twoD);
+    }
+
+    // src/hybrid_a_star.cpp:540-657 (fixed step branch :600-621, reverse :629-654)
+    std::vector<std::pair<float, float>> stepSteerPairs(const Node3D &pred, const Node3D &goal) const
+    {
+        std::vector<std::pair<float, float>> v;
+        float distance_to_goal = GetDistance(pred, goal);
+        float step_size = 0.2;
+        float first = (step_size > distance_to_goal) ? distance_to_goal : step_size;
+        for (float a : FormSteeringAngleVec(P.steering_angle, P.number_of_successors))
+            v.emplace_back(first, a);
+        if (P.reverse)
+        {
+            float rstep = -0.2;
+            float rfirst = (m_fabsf(rstep) > distance_to_goal) ? -distance_to_goal : rstep;
+            for (float a : FormSteeringAngleVec(P.steering_angle, 1))
+                v.emplace_back(rfirst, a);
+        }
+        return v;
+    }
+    // src/hybrid_a_star.cpp:659-756; emits only traversable successors
+    void createSuccessors(const Node3D &pred, int pred_id, const Node3D &goal, std::vector<Node3D> &out, int *n_checked)
+    {
+        out.clear();
+        for (const auto &pair : stepSteerPairs(pred, goal))
+        {
+            bool reverse_flag = pair.first < 0;
+            if ((double)m_fabsf(pair.first) <= 1e-3)
+                continue;
+            float steering_angle = pair.second;
+            float turning_radius = pair.first / m_fabsf(steering_angle);
+            float dx, dy;
+            int prem;
+            if (steering_angle < 0)
+            {
+                dx = turning_radius * m_sinf(m_fabsf(steering_angle));
+                dy = -(turning_radius * (1 - m_cosf(steering_angle)));
+                prem = reverse_flag ? 4 : 1;
+            }
+            else if ((double)steering_angle > 1e-3)
+            {
+                dx = turning_radius * m_sinf(m_fabsf(steering_angle));
+                dy = (turning_radius * (1 - m_cosf(steering_angle)));
+                prem = reverse_flag ? 5 : 2;
+            }
+            else
+            {
+                dx = pair.first;
+                dy = 0;
+                prem = reverse_flag ? 3 : 0;
+            }
+            Node3D s;
+            s.x = pred.x + dx * m_cosf(pred.t) - dy * m_sinf(pred.t);
+            s.y = pred.y + dx * m_sinf(pred.t) + dy * m_cosf(pred.t);
+            s.t = RadToZeroTo2P(pred.t + steering_angle);
+            s.g = pred.g;
+            s.h = 0;
+            s.reverse = reverse_flag;
+            s.prim = prem;
+            s.pred = pred_id;
+            if (n_checked)
+                ++*n_checked;
+            if (IsTraversable(s.x, s.y, s.t, true, pred.x, pred.y))
+                out.push_back(s);
+        }
+    }
+    // src/hybrid_a_star.cpp:761-811
+    float costSoFar(const Node3D &node, const Node3D &pred) const
+    {
+        float step_size = GetDistance(node, pred);
+        float g = node.g;
+        int prim = node.prim, pre_prim = pred.prim;
+        const float wt = P.penalty_turning, wc = P.penalty_change_of_direction, wr = P.penalty_reverse;
+        if (prim < 3)
+        {
+            if (pre_prim != prim)
+                g += (pre_prim > 2) ? step_size * wt * wc : step_size * wt;
+            else
+                g += step_size;
+        }
+        else
+        {
+            if (pre_prim != prim)
+                g += (pre_prim < 3) ? step_size * wt * wr * wc : step_size * wt * wr;
+            else
+                g += step_size * wr;
+        }
+        return g;
+    }
+
+    // src/hybrid_a_star.cpp:371-534.  Returns false when any sample collides.
+    bool analyticExpansion(const Node3D &start, const Node3D &goal, std::vector<Node3D> *path_vec, float *length_out)
+    {
+        if (path_vec)
+            path_vec->clear();
+        float px = start.x, py = start.y;
+        size_t n = 0;
+        if (P.curve_type == HYAS_CURVE_DUBINS)
+        {
+            float q0[3] = {start.x, start.y, start.t}, q1[3] = {goal.x, goal.y, goal.t};
+            db::Path path;
+            path.param[0] = path.param[1] = path.param[2] = 0, path.type = 0, path.rho = P.min_turning_radius;
+            for (int i = 0; i < 3; ++i)
+                path.qi[i] = q0[i];
+            db::init(q0, q1, P.min_turning_radius, &path);
+            float length = db::length(&path);
+            if (length_out)
+                *length_out = length;
+            float x = 0.f;
+            while (x < length)
+            {
+                float q[3];
+                db::sample(&path, x, q);
+                Node3D nd;
+                nd.x = q[0], nd.y = q[1], nd.t = RadToZeroTo2P(q[2]);
+                if (!IsTraversable(nd.x, nd.y, nd.t, true, px, py))
+                {
+                    if (path_vec)
+                        path_vec->clear();
+                    return false;
+                }
+                if (path_vec)
+                    path_vec->push_back(nd);
+                x = (float)((double)x + 0.2 * (double)resolution_);
+                px = nd.x, py = nd.y;
+                ++n;
+            }
+        }
+        else
+        {
+            double q0[3] = {start.x, start.y, start.t}, q1[3] = {goal.x, goal.y, goal.t};
+            double length = -1;
+            std::vector<std::array<double, 3>> pts;
+            rsSample(q0, q1, (double)P.min_turning_radius, 0.1 * (double)resolution_, length, pts);
+            if (length_out)
+                *length_out = (float)length;
+            for (auto &p : pts)
+            {
+                Node3D nd;
+                nd.x = (float)p[0], nd.y = (float)p[1], nd.t = RadToZeroTo2P((float)p[2]);
+                if (!IsTraversable(nd.x, nd.y, nd.t, true, px, py))
+                {
+                    if (path_vec)
+                        path_vec->clear();
+                    return false;
+                }
+                if (path_vec)
+                    path_vec->push_back(nd);
+                px = nd.x, py = nd.y;
+                ++n;
+            }
+        }
+        if (n == 0)
+            return false; // empty curve: path_vec.size()==0 in the reference
+        if (path_vec)
+            path_vec->push_back(goal);
+        return true;
+    }
+
+    // include/node3d.h:89-98
+    static bool nodeEq(const Node3D &a, const Node3D &b)
+    {
+        return (std::abs(a.x - b.x) < 1e-2) && (std::abs(a.y - b.y) < 1e-2) && (std::abs(a.t - b.t) < 1e-2);
+    }
+    // src/utility.cpp:2091-2109
+    void RemoveDuplicates(std::vector<Node3D> &path) const
+    {
+        if (path.empty())
+            return;
+        for (uint32_t index = 0; index < path.size() - 1; index++)
+            if ((double)GetDistance(path[index], path[index + 1]) < 1e-3)
+            {
+                path.erase(path.begin() + index);
+                index = index - 1;
+            }
+    }
+
+    struct HeapItem
+    {
+        float f;
+        uint32_t seq;
+        int node;
+    };
+    struct HeapCmp
+    { // lowest f first, then earliest push
+        bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f > b.f || (a.f == b.f && a.seq > b.seq); }
+    };
+
+    // src/hybrid_a_star.cpp:982-1018 + GetPath :41-311
+    void plan(const float s[3], const float g[3], hyas_result *res)
+    {
+        std::memset(res, 0, sizeof(*res));
+        last_path.clear();
+        last_expanded.clear();
+        const int W = cm.w, H = cm.h;
+        // src/utility.cpp:7-13: yaw normalised into [0, 2pi)
+        Node3D start, goal;
+        start.x = s[0], start.y = s[1], start.t = RadToZeroTo2P(s[2]);
+        goal.x = g[0], goal.y = g[1], goal.t = RadToZeroTo2P(g[2]);
+        // makePlan pre-checks, src/hybrid_a_star_planner.cpp:126-155
+        if (!IsTraversable(start.x, start.y, start.t, false, 0, 0))
+        {
+            res->status = HYAS_STATUS_BAD_POSE;
+            return;
+        }
+        {
+            unsigned int gx, gy;
+            if (!cm.worldToMap(goal.x, goal.y, gx, gy))
+            {
+                res->status = HYAS_STATUS_BAD_POSE;
+                return;
+            }
+            if (IsTraversable(goal.x, goal.y, goal.t, false, 0, 0) && cm.cost[gx + gy * W] > 252)
+            {
+                res->status = HYAS_STATUS_BAD_POSE;
+                return;
+            }
+        }
+        struct Cell
+        {
+            float g = 999;
+            bool o = false, c = false;
+        };
+        std::vector<Cell> nodes3D((size_t)W * H * P.headings + (size_t)H * W + W);
+        std::vector<Node3D> arena;
+        arena.reserve(4096);
+        std::vector<float> twod;
+        buildAStarCostMap(goal.x, goal.y, twod);
+        std::vector<HeapItem> heap;
+        HeapCmp cmp;
+        uint32_t seq = 0;
+        const float dh = headingDelta();
+        start.h = heuristic(start, goal, twod);
+        int N = (int)start.h;
+        start.o = true;
+        arena.push_back(start);
+        heap.push_back(HeapItem{start.g + start.h, seq++, 0});
+        int iPred = setIdx3D(start, W, H, dh, resolution_, origin_x_, origin_y_);
+        nodes3D[iPred].g = start.g, nodes3D[iPred].o = true, nodes3D[iPred].c = false;
+        int iterations = 0, counter = 0;
+        std::vector<Node3D> succ, shot, path;
+        auto trace = [&](int id) {
+            path.clear();
+            while (id >= 0)
+            {
+                path.push_back(arena[id]);
+                if (nodeEq(arena[id], start))
+                    break;
+                id = arena[id].pred;
+            }
+            std::reverse(path.begin(), path.end());
+        };
+        auto finish = [&](int status, int id) {
+            res->status = status;
+            res->g_final = arena[id].g;
+            RemoveDuplicates(path);
+            RemoveDuplicates(path); // calculatePath repeats it (:994)
+            res->path_len = (int)path.size();
+            double len = 0;
+            for (size_t i = 0; i < path.size(); ++i)
+            {
+                last_path.push_back(path[i].x), last_path.push_back(path[i].y), last_path.push_back(path[i].t);
+                if (i)
+                    len += (double)GetDistance(path[i], path[i - 1]);
+            }
+            res->path_length = (float)len;
+        };
+        while (!heap.empty())
+        {
+            HeapItem top = heap.front();
+            int pid = top.node;
+            res->nodes_explored++;
+            iPred = setIdx3D(arena[pid], W, H, dh, resolution_, origin_x_, origin_y_);
+            iterations++;
+            if (nodes3D[iPred].c)
+            {
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                heap.pop_back();
+                continue;
+            }
+            if (!nodes3D[iPred].o)
+                break; // unreachable: a pushed cell is open or closed
+            nodes3D[iPred].c = true, nodes3D[iPred].o = false;
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            heap.pop_back();
+            const Node3D nPred = arena[pid];
+            if (iterations > P.max_iterations)
+            {
+                trace(pid);
+                finish(HYAS_STATUS_MAX_ITER, pid);
+                return;
+            }
+            // src/utility.cpp:1132-1163
+            {
+                float distance = GetDistance(nPred, goal);
+                float distance_range = P.goal_range * resolution_;
+                float angle_range = (float)(2 * kPi / P.headings);
+                if (distance < distance_range && m_fabsf(RadNormalization(nPred.t - goal.t)) <= angle_range)
+                {
+                    trace(pid);
+                    finish(HYAS_STATUS_GOAL, pid);
+                    return;
+                }
+            }
+            res->nodes_expanded++;
+            last_expanded.push_back(iPred);
+            if (P.analytical_expansion)
+            {
+                bool shoot = false;
+                if (P.analytical_expansion_every_point)
+                    shoot = true;
+                else if (counter == N)
+                {
+                    N = (int)nPred.h;
+                    counter = 0;
+                    shoot = true;
+                }
+                else
+                    counter++;
+                float slen = 0;
+                if (shoot && analyticExpansion(nPred, goal, &shot, &slen))
+                {
+                    trace(pid);
+                    path.insert(path.end(), shot.begin(), shot.end());
+                    res->shot_length = slen;
+                    finish(HYAS_STATUS_SHOT, pid);
+                    return;
+                }
+            }
+            createSuccessors(nPred, pid, goal, succ, &res->successors);
+            for (Node3D &nSucc : succ)
+            {
+                // DuplicateCheck, src/hybrid_a_star.cpp:968-980
+                bool dup = false;
+                for (const HeapItem &e : heap)
+                {
+                    const Node3D &q = arena[e.node];
+                    if ((double)m_fabsf(q.x - nSucc.x) < 0.05 && (double)m_fabsf(q.y - nSucc.y) < 0.05 &&
+                        m_fabsf(q.t - nSucc.t) < ConvertDegToRad(3))
+                    {
+                        dup = true;
+                        break;
+                    }
+                }
+                if (dup)
+                    continue;
+                int iSucc = setIdx3D(nSucc, W, H, dh, resolution_, origin_x_, origin_y_);
+                // second IsTraversable of the reference (:260): same verdict
+                if (!IsTraversable(nSucc.x, nSucc.y, nSucc.t, true, nPred.x, nPred.y))
+                    continue;
+                if (nodes3D[iSucc].c)
+                    continue;
+                nSucc.g = costSoFar(nSucc, nPred);
+                float newG = nSucc.g;
+                if (!nodes3D[iSucc].o || newG < nodes3D[iSucc].g)
+                {
+                    nSucc.h = heuristic(nSucc, goal, twod);
+                    if (iPred == iSucc)
+                    {
+                        if (nSucc.g + nSucc.h > nPred.g + nPred.h + P.tie_breaker)
+                            continue;
+                        nSucc.pred = nPred.pred;
+                    }
+                    nSucc.o = true, nSucc.c = false;
+                    nodes3D[iSucc].g = nSucc.g, nodes3D[iSucc].o = true, nodes3D[iSucc].c = false;
+                    arena.push_back(nSucc);
+                    heap.push_back(HeapItem{nSucc.g + nSucc.h, seq++, (int)arena.size() - 1});
+                    std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+            }
+        }
+        res->status = HYAS_STATUS_NO_PATH;
+    }
+};
+
+} // namespace orc
+
+// ======================================================================= C API
+using orc::Ctx;
+extern "C" {
+
+void *orc_create(const hyas_params *p)
+{
+    Ctx *c = new Ctx();
+    c->P = *p;
+    return c;
+}
+void orc_destroy(void *h) { delete (Ctx *)h; }
+
+int orc_set_costmap(void *h, const uint8_t *charmap, uint32_t w, uint32_t hgt, double res, double ox, double oy,
+                    int build_table, int nthreads)
+{
+    Ctx *c = (Ctx *)h;
+    c->cm.w = w, c->cm.h = hgt, c->cm.res = res, c->cm.ox = ox, c->cm.oy = oy;
+    c->cm.cost.assign(charmap, charmap + (size_t)w * hgt);
+    c->resolution_ = (float)res, c->origin_x_ = (float)ox, c->origin_y_ = (float)oy;
+    c->translateCostmap();
+    c->SetObstacleVec();
+    c->SetInRangeObstacle();
+    c->buildFootprintTable();
+    if (build_table)
+        c->buildTable(c->P.curve_type, nthreads);
+    return 0;
+}
+
+int orc_num_obstacles(void *h) { return (int)((Ctx *)h)->obstacle_vec_.size(); }
+// 8 floats per obstacle: the 4 distinct vertices
+int orc_get_obstacles(void *h, float *out, size_t cap)
+{
+    Ctx *c = (Ctx *)h;
+    size_t n = std::min(cap, c->obstacle_vec_.size());
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 4; ++k)
+            out[i * 8 + 2 * k] = c->obstacle_vec_[i][k].x, out[i * 8 + 2 * k + 1] = c->obstacle_vec_[i][k].y;
+    return (int)c->obstacle_vec_.size();
+}
+// number of in-range obstacles of grid key `key`, -1 if the key is absent
+int orc_in_range_count(void *h, uint32_t key)
+{
+    Ctx *c = (Ctx *)h;
+    auto it = c->in_range_obstacle_map_.find(key);
+    return it == c->in_range_obstacle_map_.end() ? -1 : (int)it->second.size();
+}
+
+int orc_collision_batch(void *h, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *free_out)
+{
+    Ctx *c = (Ctx *)h;
+    for (size_t i = 0; i < n; ++i)
+    {
+        float x = xyt[3 * i], y = xyt[3 * i + 1], t = xyt[3 * i + 2];
+        if (mode == HYAS_MODE_FOOTPRINT)
+            free_out[i] = c->footprintTest(x, y, t);
+        else
+            free_out[i] = c->IsTraversable(x, y, t, pred_xy != nullptr, pred_xy ? pred_xy[2 * i] : 0, pred_xy ? pred_xy[2 * i + 1] : 0);
+    }
+    return 0;
+}
+
+int orc_footprint_table(void *h, int32_t *out, size_t cap)
+{
+    Ctx *c = (Ctx *)h;
+    size_t n = std::min(cap, c->fp.size());
+    std::memcpy(out, c->fp.data(), n * sizeof(orc::FpConfig));
+    return (int)c->fp.size();
+}
+
+int orc_num_successors(void *h)
+{
+    Ctx *c = (Ctx *)h;
+    return (int)orc::FormSteeringAngleVec(c->P.steering_angle, c->P.number_of_successors).size() + (c->P.reverse ? 1 : 0);
+}
+
+int orc_expand_batch(void *h, const hyas_node *preds, const hyas_goal *goals, const float *twod, size_t n,
+                     hyas_succ *out, uint8_t *count)
+{
+    Ctx *c = (Ctx *)h;
+    const int K = orc_num_successors(h);
+    const size_t cells = c->twodSize();
+    std::vector<orc::Node3D> succ;
+    std::vector<float> td;
+    for (size_t i = 0; i < n; ++i)
+    {
+        orc::Node3D p, g;
+        p.x = preds[i].x, p.y = preds[i].y, p.t = preds[i].t, p.g = preds[i].g, p.prim = preds[i].prim;
+        g.x = goals[i].x, g.y = goals[i].y, g.t = goals[i].t;
+        if (twod)
+            td.assign(twod + i * cells, twod + (i + 1) * cells);
+        c->createSuccessors(p, -1, g, succ, nullptr);
+        count[i] = (uint8_t)succ.size();
+        for (int k = 0; k < K; ++k)
+        {
+            hyas_succ &o = out[i * K + k];
+            std::memset(&o, 0, sizeof(o));
+            if ((size_t)k >= succ.size())
+                continue;
+            orc::Node3D s = succ[k];
+            s.g = c->costSoFar(s, p);
+            s.h = c->heuristic(s, g, td);
+            o.x = s.x, o.y = s.y, o.t = s.t, o.g = s.g, o.h = s.h, o.prim = (int8_t)s.prim, o.free = 1;
+            o.idx = orc::setIdx3D(s, c->cm.w, c->cm.h, c->headingDelta(), c->resolution_, c->origin_x_, c->origin_y_);
+        }
+    }
+    return 0;
+}
+
+int orc_shot_batch(void *h, const hyas_node *nodes, const hyas_goal *goals, size_t n, uint8_t *ok, float *len)
+{
+    Ctx *c = (Ctx *)h;
+    for (size_t i = 0; i < n; ++i)
+    {
+        orc::Node3D p, g;
+        p.x = nodes[i].x, p.y = nodes[i].y, p.t = nodes[i].t;
+        g.x = goals[i].x, g.y = goals[i].y, g.t = goals[i].t;
+        float l = 0;
+        ok[i] = c->analyticExpansion(p, g, nullptr, &l);
+        len[i] = l;
+    }
+    return 0;
+}
+
+int orc_twod_size(void *h) { return (int)((Ctx *)h)->twodSize(); }
+int orc_flood(void *h, const hyas_goal *goal, float *out)
+{
+    Ctx *c = (Ctx *)h;
+    std::vector<float> m;
+    c->buildAStarCostMap(goal->x, goal->y, m);
+    std::memcpy(out, m.data(), m.size() * sizeof(float));
+    return 0;
+}
+
+int orc_table_dims(void *h, int32_t *nx, int32_t *ny, int32_t *ns)
+{
+    Ctx *c = (Ctx *)h;
+    std::vector<float> xs, ys, ts;
+    c->tableAxes(xs, ys, ts);
+    *nx = (int)xs.size(), *ny = (int)ys.size(), *ns = (int)ts.size();
+    return 0;
+}
+// raw costs in [slice][iy][ix] order for heading-loop iterations [b, e)
+int orc_table_build(void *h, int curve, int b, int e, float *out)
+{
+    Ctx *c = (Ctx *)h;
+    std::vector<float> xs, ys, ts;
+    c->tableAxes(xs, ys, ts);
+    for (int k = b; k < e; ++k)
+        for (size_t j = 0; j < ys.size(); ++j)
+            for (size_t i = 0; i < xs.size(); ++i)
+                out[((size_t)(k - b) * ys.size() + j) * xs.size() + i] = (float)c->curveDistance(curve, xs[i], ys[j], ts[k]);
+    return 0;
+}
+int orc_build_table(void *h, int curve, int nthreads)
+{
+    ((Ctx *)h)->buildTable(curve, nthreads);
+    return 0;
+}
+int orc_table_lookup(void *h, const float *xyt, size_t n, float *cost)
+{
+    Ctx *c = (Ctx *)h;
+    for (size_t i = 0; i < n; ++i)
+        cost[i] = c->tableCost(xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]);
+    return 0;
+}
+// sum over emplaced keys (double) and their count, for checksum pins
+double orc_table_checksum(void *h, int64_t *count)
+{
+    Ctx *c = (Ctx *)h;
+    double s = 0;
+    int64_t n = 0;
+    for (float v : c->table)
+        if (v == v)
+            s += (double)v, ++n;
+    if (count)
+        *count = n;
+    return s;
+}
+
+int orc_plan(void *h, const float *start, const float *goal, hyas_result *res)
+{
+    ((Ctx *)h)->plan(start, goal, res);
+    return 0;
+}
+int orc_get_path(void *h, float *xyt, size_t cap)
+{
+    Ctx *c = (Ctx *)h;
+    size_t n = c->last_path.size() / 3;
+    std::memcpy(xyt, c->last_path.data(), std::min(cap, n) * 3 * sizeof(float));
+    return (int)n;
+}
+int orc_get_expanded(void *h, int32_t *idx, size_t cap)
+{
+    Ctx *c = (Ctx *)h;
+    size_t n = c->last_expanded.size();
+    std::memcpy(idx, c->last_expanded.data(), std::min(cap, n) * sizeof(int32_t));
+    return (int)n;
+}
+
+// ---- raw function access for known-answer tests --------------------------
+double orc_rs_distance(double rho, const double *q0, const double *q1) { return rho * orc::reedsShepp(q0, q1, rho).total; }
+int orc_rs_path(double rho, const double *q0, const double *q1, int *type, double *len5)
+{
+    orc::RsPath p = orc::reedsShepp(q0, q1, rho);
+    *type = p.type;
+    for (int i = 0; i < 5; ++i)
+        len5[i] = p.len[i];
+    return 0;
+}
+int orc_rs_sample(double rho, const double *q0, const double *q1, double step, double *length, double *pts, size_t cap)
+{
+    std::vector<std::array<double, 3>> v;
+    orc::rsSample(q0, q1, rho, step, *length, v);
+    for (size_t i = 0; i < v.size() && i < cap; ++i)
+        pts[3 * i] = v[i][0], pts[3 * i + 1] = v[i][1], pts[3 * i + 2] = v[i][2];
+    return (int)v.size();
+}
+// out: [type, p0, p1, p2, length] as floats; returns dubins_init's code
+int orc_dubins(const float *q0, const float *q1, float rho, float *out)
+{
+    orc::db::Path p;
+    p.param[0] = p.param[1] = p.param[2] = 0, p.type = -1;
+    int rc = orc::db::init(q0, q1, rho, &p);
+    out[0] = (float)p.type, out[1] = p.param[0], out[2] = p.param[1], out[3] = p.param[2], out[4] = orc::db::length(&p);
+    return rc;
+}
+int orc_dubins_sample(const float *q0, const float *q1, float rho, float t, float *q)
+{
+    orc::db::Path p;
+    if (orc::db::init(q0, q1, rho, &p) != 0)
+        return -1;
+    return orc::db::sample(&p, t, q);
+}
+
+// Utility:: known-answer access; op codes documented in tests/test_oracle_kat.py
+double orc_utility(int op, const float *a)
+{
+    using namespace orc;
+    auto P = [&](int i) { return V2{a[2 * i], a[2 * i + 1]}; };
+    switch (op)
+    {
+    case 0:
+        return IsIntersect(P(0), P(1), P(2), P(3));
+    case 1:
+    {
+        V2 r = FindIntersectionPoint(P(0), P(1), P(2), P(3));
+        return (double)r.x * 100000.0 + (double)r.y;
+    }
+    case 2:
+        return OnSegment(P(0), P(1), P(2));
+    case 3:
+        return IsAboveSegment(P(0), P(1), P(2));
+    case 4:
+    { // polygon = rectangle (0..3) closed, point 4
+        Polygon poly{P(0), P(1), P(2), P(3), P(0)};
+        return IsInsidePolygon(poly, P(4));
+    }
+    case 5:
+        return GetDistanceFromPolygonToPoint(CreatePolygon(P(0)), P(1));
+    case 6:
+        return GetDistanceFromSegmentToPoint(P(0), P(1), P(2));
+    case 7:
+        return CreatePolygon(P(0), a[2], a[3], a[4])[(int)a[5]].x;
+    case 8:
+        return IsPolygonIntersectWithPolygon(CreatePolygon(P(0)), CreatePolygon(P(1)));
+    case 9:
+        return GetDistanceFromPolygonToSegment(CreatePolygon(P(0)), P(1), P(2));
+    case 10:
+        return (double)CombinePolygon(CreatePolygon(P(0)), CreatePolygon(P(1))).size();
+    case 11:
+        return IsSegmentIntersectWithPolygon(CreatePolygon(P(0)), P(1), P(2));
+    case 12:
+        return GetUnitVector(P(0), P(1)).x * 10.0 + GetUnitVector(P(0), P(1)).y;
+    case 13:
+        return IsPointOnLine(P(0), P(1), P(2));
+    case 14:
+        return GetDistanceFromPointToLine(P(0), P(1), P(2));
+    case 15:
+        return RadToZeroTo2P(a[0]);
+    case 16:
+        return RadNormalization(a[0]);
+    case 17:
+        return ConvertDegToRad(a[0]);
+    default:
+        return -12345;
+    }
+}
+
+// Wall-clock helper for bench.py's cpu_baseline: plans queries [0, n) one at a
+// time on this thread; returns seconds, fills totals.
+double orc_plan_many(void *h, const float *starts, const float *goals, size_t n, hyas_result *res)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < n; ++i)
+        ((Ctx *)h)->plan(starts + 3 * i, goals + 3 * i, res + i);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}

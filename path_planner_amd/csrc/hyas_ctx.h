@@ -1,0 +1,89 @@
+// hyas_ctx.h -- the context behind the C ABI: host copies of the map, device
+// buffers, staging memory and kernel timers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "hyas_kernels.h"
+
+struct hyas_ctx
+{
+    hyas_params P{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_map = false, have_table = false, grid_only = false;
+
+    // host-side map state
+    uint32_t w = 0, h = 0;
+    double res = 1, ox = 0, oy = 0;
+    std::vector<uint8_t> charmap;
+    std::vector<hyas::Quad> quads;
+    std::vector<uint32_t> cell_off;
+    std::vector<uint16_t> cell_idx;
+    std::vector<int32_t> fp; // footprint table, 129 ints per entry
+    std::vector<float> tab_xs, tab_ys, tab_ts;
+    uint64_t table_size = 0;
+    uint32_t seg_cap = 0;
+    size_t twod_size = 0; // floats per 2D cost map
+
+    // device mirrors
+    hyas::DevMap dm{}; // pointers below, as the kernels see them
+    uint8_t *d_charmap = nullptr;
+    hyas::Quad *d_quads = nullptr;
+    uint32_t *d_cell_off = nullptr;
+    uint16_t *d_cell_idx = nullptr;
+    int32_t *d_fp = nullptr;
+    float *d_table = nullptr;
+    float *d_tab_xs = nullptr, *d_tab_ys = nullptr, *d_tab_ts = nullptr;
+    double *d_seg = nullptr;
+
+    // growable scratch: device + pinned host, reused by every batched call
+    void *d_scratch = nullptr;
+    size_t d_scratch_bytes = 0;
+    void *h_scratch = nullptr;
+    size_t h_scratch_bytes = 0;
+    float *d_twod = nullptr;
+    size_t d_twod_bytes = 0;
+
+    // results of the last hyas_plan_batch
+    std::vector<std::vector<float>> paths;
+    std::vector<std::vector<int32_t>> expanded;
+
+    // kernel timing, HIP events on `stream`
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double k_ms[5] = {0, 0, 0, 0, 0};
+    int64_t k_launches[5] = {0, 0, 0, 0, 0};
+    unsigned long long *d_stats = nullptr; // samples tested by the step kernel
+
+    int fail(int code, const std::string &msg)
+    {
+        err = msg;
+        return code;
+    }
+};
+
+namespace hyas
+{
+// hipError -> HYAS_E*, records the message in the context
+int hip_fail(hyas_ctx *c, hipError_t e, const char *what);
+#define HYAS_HIP(c, call)                                    \
+    do                                                       \
+    {                                                        \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess)                                \
+            return hyas::hip_fail((c), e_, #call);           \
+    } while (0)
+
+int ensure_scratch(hyas_ctx *c, size_t dev_bytes, size_t host_bytes);
+int ensure_twod(hyas_ctx *c, size_t bytes);
+void timer_begin(hyas_ctx *c);
+void timer_end(hyas_ctx *c, int which); // call after the stream has been synchronised
+void reset_timers(hyas_ctx *c);
+
+// host restatements used by the search driver (hyas_host.cpp)
+void flood_2d(const hyas_ctx *c, float gx, float gy, float *out /* twod_size floats */);
+int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out);
+} // namespace hyas

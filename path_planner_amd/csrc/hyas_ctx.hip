@@ -1,0 +1,950 @@
+// hyas_ctx.hip -- C ABI (include/hyas.h): context life cycle, map ingest,
+// heuristic-table build and the batched kernel entry points.
+#include "hyas_ctx.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+using namespace hyas;
+
+namespace hyas
+{
+
+int hip_fail(hyas_ctx *c, hipError_t e, const char *what)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    if (c)
+        c->err = buf;
+    return (e == hipErrorOutOfMemory) ? HYAS_ENOMEM : HYAS_ENODEV;
+}
+
+int ensure_scratch(hyas_ctx *c, size_t dev_bytes, size_t host_bytes)
+{
+    if (dev_bytes > c->d_scratch_bytes)
+    {
+        if (c->d_scratch)
+            HYAS_HIP(c, hipFree(c->d_scratch));
+        c->d_scratch = nullptr, c->d_scratch_bytes = 0;
+        size_t want = dev_bytes + dev_bytes / 2;
+        HYAS_HIP(c, hipMalloc(&c->d_scratch, want));
+        c->d_scratch_bytes = want;
+    }
+    if (host_bytes > c->h_scratch_bytes)
+    {
+        if (c->h_scratch)
+            HYAS_HIP(c, hipHostFree(c->h_scratch));
+        c->h_scratch = nullptr, c->h_scratch_bytes = 0;
+        size_t want = host_bytes + host_bytes / 2;
+        HYAS_HIP(c, hipHostMalloc(&c->h_scratch, want, hipHostMallocDefault));
+        c->h_scratch_bytes = want;
+    }
+    return HYAS_OK;
+}
+
+int ensure_twod(hyas_ctx *c, size_t bytes)
+{
+    if (bytes > c->d_twod_bytes)
+    {
+        if (c->d_twod)
+            HYAS_HIP(c, hipFree(c->d_twod));
+        c->d_twod = nullptr, c->d_twod_bytes = 0;
+        HYAS_HIP(c, hipMalloc((void **)&c->d_twod, bytes));
+        c->d_twod_bytes = bytes;
+    }
+    return HYAS_OK;
+}
+
+void timer_begin(hyas_ctx *c) { (void)hipEventRecord(c->ev0, c->stream); }
+void timer_end(hyas_ctx *c, int which)
+{
+    (void)hipEventRecord(c->ev1, c->stream);
+    (void)hipEventSynchronize(c->ev1);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
+        c->k_ms[which] += ms;
+    c->k_launches[which] += 1;
+}
+void reset_timers(hyas_ctx *c)
+{
+    for (int i = 0; i < 5; ++i)
+        c->k_ms[i] = 0, c->k_launches[i] = 0;
+}
+
+// ------------------------------------------------------------------ ingest
+// nav_msgs::OccupancyGrid value of a costmap cost, src/utility.cpp:185-204
+static int8_t occupancy_of(uint8_t cost)
+{
+    if (cost == 0)
+        return 0;
+    if (cost == 253)
+        return 99;
+    if (cost == 254)
+        return 100;
+    if (cost == 255)
+        return -1;
+    return (int8_t)(1 + (97 * ((int)cost - 1)) / 251);
+}
+
+static Quad make_quad(const float vx[4], const float vy[4])
+{
+    Quad q;
+    for (int i = 0; i < 4; ++i)
+        q.vx[i] = vx[i], q.vy[i] = vy[i];
+    q.xmin = *std::min_element(vx, vx + 4), q.xmax = *std::max_element(vx, vx + 4);
+    q.ymin = *std::min_element(vy, vy + 4), q.ymax = *std::max_element(vy, vy + 4);
+    return q;
+}
+
+// Utility::IsPolygonInNeighbor, src/utility.cpp:999-1012: any bit-equal vertex
+static bool share_vertex(const Quad &a, const Quad &b)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (a.vx[i] == b.vx[j] && a.vy[i] == b.vy[j])
+                return true;
+    return false;
+}
+
+// Utility::CombinePolygon(cur, prev), src/utility.cpp:1014-1058.  The result is
+// a general quadrilateral when the two cells only touch at a corner.
+static bool combine(const Quad &p1, const Quad &p2, Quad &out)
+{
+    float vx[4], vy[4];
+    auto pick = [&](int k, const Quad &q, int i) { vx[k] = q.vx[i], vy[k] = q.vy[i]; };
+    if (p2.vy[0] > p1.vy[0])
+        pick(0, p1, 0), pick(1, p1, 1), pick(2, p2, 2), pick(3, p2, 3);
+    else if (p2.vx[0] < p1.vx[0])
+        pick(0, p2, 0), pick(1, p1, 1), pick(2, p1, 2), pick(3, p2, 3);
+    else if (p2.vy[0] < p1.vy[0])
+        pick(0, p2, 0), pick(1, p2, 1), pick(2, p1, 2), pick(3, p1, 3);
+    else if (p2.vx[0] > p1.vx[0])
+        pick(0, p1, 0), pick(1, p2, 1), pick(2, p2, 2), pick(3, p1, 3);
+    else
+        return false;
+    out = make_quad(vx, vy);
+    return true;
+}
+
+// The float loop variables of src/collisiondetection.cpp:268-303 / :324-348.
+static void cell_axes(const hyas_ctx *c, std::vector<float> &xs, std::vector<float> &ys)
+{
+    const float res = (float)c->res, ox = (float)c->ox, oy = (float)c->oy;
+    const float x_limit = ox + c->w * res, y_limit = oy + c->h * res;
+    for (float x = ox; x < x_limit; x = x + res)
+        xs.push_back(x);
+    for (float y = oy; y < y_limit; y = y + res)
+        ys.push_back(y);
+}
+
+// CollisionDetection::SetObstacleVec, src/collisiondetection.cpp:262-317
+static void extract_obstacles(hyas_ctx *c, const std::vector<float> &xs, const std::vector<float> &ys)
+{
+    const float res = (float)c->res;
+    DevMap hm = c->dm; // only the scalar members are used by grid_key()
+    c->quads.clear();
+    for (float x : xs)
+        for (float y : ys)
+        {
+            uint32_t gi = grid_key(hm, x, y);
+            if (gi >= c->charmap.size() || occupancy_of(c->charmap[gi]) == 0)
+                continue;
+            // CreatePolygon(origin, res, res), src/utility.cpp:457-474
+            const float vx[4] = {x, res + x, res + x, x};
+            const float vy[4] = {y, y, y + res, y + res};
+            Quad cur = make_quad(vx, vy);
+            if (!c->quads.empty() && share_vertex(c->quads.back(), cur))
+            {
+                Quad merged;
+                if (combine(cur, c->quads.back(), merged))
+                    c->quads.back() = merged;
+                // an un-mergeable neighbour leaves an EMPTY polygon in the
+                // reference; it cannot arise from grid cells, keep the old one
+            }
+            else
+                c->quads.push_back(cur);
+        }
+}
+
+// --------------------------------------------------- footprint-list table
+// Rasterises the rotated vehicle rectangle into a bb x bb cell box for every
+// sub-cell offset and heading, as Lookup::collisionLookup does
+// (include/lookup.h:30-284): edges are traced cell by cell with a DDA walk,
+// then each row is filled between its outermost marked cells.
+namespace fpt
+{
+struct Pt
+{
+    float x, y;
+};
+static inline int sgn(float v) { return v >= 0 ? 1 : -1; }
+
+static void trace_edge(std::vector<char> &box, int bb, Pt a, Pt b) // :153-213
+{
+    int X = (int)a.x, Y = (int)a.y;
+    box[Y * bb + X] = 1;
+    const float tx = b.x - a.x, ty = b.y - a.y;
+    const int stepX = sgn(tx), stepY = sgn(ty);
+    const float tDeltaX = (tx != 0) ? 1.f / std::abs(tx) : 1000;
+    const float tDeltaY = (ty != 0) ? 1.f / std::abs(ty) : 1000;
+    float tMaxX = (stepX > 0) ? tDeltaX * (1 - (a.x - (long)a.x)) : tDeltaX * (a.x - (long)a.x);
+    float tMaxY = (stepY > 0) ? tDeltaY * (1 - (a.y - (long)a.y)) : tDeltaY * (a.y - (long)a.y);
+    const int ex = (int)b.x, ey = (int)b.y;
+    while (ex != X || ey != Y)
+    {
+        if (tMaxX < tMaxY && std::abs(X + stepX - ex) < std::abs(X - ex))
+        {
+            tMaxX = tMaxX + tDeltaX;
+            X = X + stepX;
+        }
+        else if (tMaxY < tMaxX && std::abs(Y + stepY - ey) < std::abs(Y - ey))
+        {
+            tMaxY = tMaxY + tDeltaY;
+            Y = Y + stepY;
+        }
+        else if (2 >= std::abs(X - ex) + std::abs(Y - ey))
+        {
+            if (std::abs(X - ex) > std::abs(Y - ey))
+                X = X + stepX;
+            else
+                Y = Y + stepY;
+        }
+        else
+            break;
+        box[Y * bb + X] = 1;
+    }
+}
+
+static void build(const hyas_params &P, std::vector<int32_t> &out)
+{
+    const float cell = P.fp_cell_size;
+    const double width = P.fp_width, length = P.fp_length;
+    const int bb = (int)std::ceil((std::sqrt(width * width + length * length) + 4) / cell); // constants.h:56
+    const int pr = P.position_resolution, headings = P.headings;
+    const float dtheta = (float)(2 * HY_PI / (double)(float)headings); // constants.h:46
+    out.assign((size_t)pr * pr * headings * 129, 0);
+    std::vector<char> box((size_t)bb * bb);
+    // scan-fill state that the reference keeps alive across rows AND entries
+    int first_marked = 0, last_marked = 0;
+    for (int q = 0; q < pr * pr; ++q)
+    {
+        const float offx = 1.f / pr * (q % pr), offy = 1.f / pr * (q / pr); // :87-92
+        Pt c{(float)bb / 2 + offx, (float)bb / 2 + offy};
+        const double hl = length / 2 / (double)cell, hw = width / 2 / (double)cell;
+        const Pt corner[4] = {{(float)((double)c.x - hl), (float)((double)c.y - hw)},
+                              {(float)((double)c.x - hl), (float)((double)c.y + hw)},
+                              {(float)((double)c.x + hl), (float)((double)c.y + hw)},
+                              {(float)((double)c.x + hl), (float)((double)c.y - hw)}};
+        float theta = 0;
+        for (int o = 0; o < headings; ++o)
+        {
+            std::fill(box.begin(), box.end(), 0);
+            Pt r[4];
+            const float ct = hy_cosf(theta), st = hy_sinf(theta);
+            for (int j = 0; j < 4; ++j)
+            {
+                const float rx = corner[j].x - c.x, ry = corner[j].y - c.y;
+                r[j].x = rx * ct - ry * st + c.x;
+                r[j].y = rx * st + ry * ct + c.y;
+            }
+            theta += dtheta;
+            for (int k = 0; k < 4; ++k)
+                trace_edge(box, bb, r[k], r[(k + 1) & 3]);
+            for (int i = 0; i < bb; ++i) // :216-240
+            {
+                bool inside = false;
+                for (int j = 0; j < bb; ++j)
+                {
+                    for (int k = 0; k < bb; ++k)
+                        if (box[i * bb + k])
+                        {
+                            if (!inside)
+                                first_marked = k, inside = true;
+                            last_marked = k;
+                        }
+                    if (j > first_marked && j < last_marked && inside)
+                        box[i * bb + j] = 1;
+                }
+            }
+            int32_t *e = &out[((size_t)q * headings + o) * 129];
+            int count = 0;
+            for (int i = 0; i < bb; ++i)
+                for (int j = 0; j < bb; ++j)
+                    if (box[i * bb + j])
+                    {
+                        if (count < 64)
+                            e[1 + 2 * count] = j - (int)c.x, e[2 + 2 * count] = i - (int)c.y;
+                        ++count;
+                    }
+            e[0] = count;
+        }
+    }
+}
+} // namespace fpt
+
+// ------------------------------------------------------- 2D cost-to-goal
+// HybridAStar::BuildAStarCostMap, src/hybrid_a_star.cpp:1020-1074, with
+// AStar::CreateSuccessor(pred, 8) (src/a_star.cpp:214-277; step = resolution,
+// :340-346) and AStar::UpdateCostSoFar (:281-288).  The open queue keeps the
+// priority a cell had when it was first pushed (the parent's cost) and its
+// comparator is `>=` (include/hybrid_a_star.h:45-53), so the very same
+// std::priority_queue is used here to reproduce the pop order.
+struct FloodCmp
+{
+    bool operator()(const std::pair<int, double> &l, const std::pair<int, double> &r) const { return l.second >= r.second; }
+};
+struct FloodCell
+{
+    float x, y, g, px, py;
+    uint8_t state; // 0 unseen, 1 open (no parent), 2 open (has parent)
+};
+
+void flood_2d(const hyas_ctx *c, float gx, float gy, float *out)
+{
+    const DevMap &m = c->dm; // host code only touches its scalar members
+    const size_t N = c->twod_size;
+    std::fill(out, out + N, -1.f);
+    std::vector<FloodCell> cells(N);
+    for (auto &cl : cells)
+        cl.state = 0;
+    std::priority_queue<std::pair<int, double>, std::vector<std::pair<int, double>>, FloodCmp> pq;
+    auto in_range = [&](int id) { return id >= 0 && (size_t)id < N; };
+    int gid = idx_2d(m, gx, gy);
+    if (!in_range(gid))
+        return;
+    cells[gid] = FloodCell{gx, gy, 0.f, 0.f, 0.f, 1};
+    pq.emplace(gid, 0.0);
+    const float step = m.res_f;
+    const float delta[3] = {-step, 0, step};
+    while (!pq.empty())
+    {
+        const int id = pq.top().first;
+        pq.pop();
+        FloodCell &cur = cells[id];
+        if (cur.state == 2)
+            cur.g = cur.g + normf(sub(f2(cur.x, cur.y), f2(cur.px, cur.py)));
+        const int cid = idx_2d(m, cur.x, cur.y);
+        if (in_range(cid) && out[cid] < 0)
+            out[cid] = cur.g;
+        const float cx = cur.x, cy = cur.y, cg = cur.g;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+            {
+                if (delta[i] == 0 && delta[j] == 0)
+                    continue;
+                const float xs = cx + delta[i], ys = cy + delta[j];
+                if (!on_grid(m, xs, ys))
+                    continue;
+                const int nid = idx_2d(m, xs, ys);
+                if (!in_range(nid))
+                    continue;
+                if (out[nid] >= 0)
+                    continue;
+                FloodCell &nb = cells[nid];
+                if (nb.state != 0)
+                {
+                    if (nb.g > cg)
+                        nb.g = cg, nb.px = cx, nb.py = cy, nb.state = 2;
+                }
+                else
+                {
+                    nb = FloodCell{xs, ys, cg, cx, cy, 2};
+                    pq.emplace(nid, (double)cg);
+                }
+            }
+    }
+}
+
+static void free_map(hyas_ctx *c)
+{
+    void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    c->d_charmap = nullptr, c->d_quads = nullptr, c->d_cell_off = nullptr, c->d_cell_idx = nullptr, c->d_fp = nullptr;
+    c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
+    c->have_map = c->have_table = false;
+}
+
+template <typename T>
+static int upload(hyas_ctx *c, T *&dst, const std::vector<T> &src, size_t min_elems = 1)
+{
+    size_t n = std::max(src.size(), min_elems);
+    HYAS_HIP(c, hipMalloc((void **)&dst, n * sizeof(T)));
+    if (!src.empty())
+        HYAS_HIP(c, hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HYAS_OK;
+}
+
+} // namespace hyas
+
+// ============================================================== C ABI
+extern "C" {
+
+void hyas_default_params(hyas_params *p)
+{
+    std::memset(p, 0, sizeof *p);
+    p->position_resolution = 10, p->headings = 72, p->cd_min_turning_radius = 6, p->curve_type = 0;
+    p->vehicle_width = 1, p->vehicle_length = 2, p->obstacle_detection_range = 5, p->map_boundary_obstacle = 0;
+    p->number_of_successors = 3, p->adaptive_steering_angle_and_step_size = 0, p->adaptive_step_size = 0;
+    p->analytical_expansion_every_point = 1, p->analytical_expansion = 1;
+    p->penalty_turning = 1.05f, p->penalty_reverse = 1, p->penalty_change_of_direction = 2, p->reverse = 0;
+    p->max_iterations = 10000, p->steering_angle = 5, p->goal_range = 1e-3f, p->tie_breaker = 0.01f;
+    p->min_turning_radius = 6, p->fp_width = 0.18, p->fp_length = 0.22, p->fp_cell_size = 1;
+}
+
+void hyas_hot_path_params(hyas_params *p)
+{
+    hyas_default_params(p);
+    p->curve_type = HYAS_CURVE_RS, p->number_of_successors = 5, p->steering_angle = 5, p->reverse = 1;
+}
+
+static bool params_ok(const hyas_params *p, std::string &why)
+{
+    if (p->adaptive_steering_angle_and_step_size || p->adaptive_step_size)
+        why = "adaptive step/steering modes are not part of this path (fixed-step branch only)";
+    else if (p->map_boundary_obstacle)
+        why = "map_boundary_obstacle is not supported";
+    else if (p->headings < 1 || p->headings > 720 || p->position_resolution < 1 || p->position_resolution > 64)
+        why = "headings / position_resolution out of range";
+    else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS)
+        why = "curve_type must be 0 (Dubins) or 1 (Reeds-Shepp)";
+    else if (!(p->min_turning_radius > 0) || !(p->cd_min_turning_radius > 0))
+        why = "turning radius must be positive";
+    else if (p->number_of_successors < 1 || 1 + 2 * ((p->number_of_successors - 1) / 2) + (p->reverse ? 1 : 0) > HYAS_MAX_SUCC)
+        why = "number_of_successors out of range";
+    else
+        return true;
+    return false;
+}
+
+hyas_ctx *hyas_create(const hyas_params *params, int device)
+{
+    if (!params)
+        return nullptr;
+    std::string why;
+    if (!params_ok(params, why))
+    {
+        fprintf(stderr, "hyas_create: %s\n", why.c_str());
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    {
+        fprintf(stderr, "hyas_create: no HIP device %d (found %d)\n", device, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess)
+        return nullptr;
+    hyas_ctx *c = new hyas_ctx();
+    c->P = *params;
+    c->device = device;
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void **)&c->d_stats, sizeof(unsigned long long)) != hipSuccess)
+    {
+        fprintf(stderr, "hyas_create: stream/event creation failed\n");
+        delete c;
+        return nullptr;
+    }
+    (void)hipMemset(c->d_stats, 0, sizeof(unsigned long long));
+    return c;
+}
+
+void hyas_destroy(hyas_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_map(c);
+    if (c->d_scratch)
+        (void)hipFree(c->d_scratch);
+    if (c->h_scratch)
+        (void)hipHostFree(c->h_scratch);
+    if (c->d_twod)
+        (void)hipFree(c->d_twod);
+    if (c->d_stats)
+        (void)hipFree(c->d_stats);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *hyas_last_error(const hyas_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int hyas_num_successors(const hyas_ctx *c) { return c ? c->dm.n_succ : HYAS_EINVAL; }
+
+static void fill_motion_set(hyas_ctx *c)
+{
+    // Utility::FormSteeringAngleVec (src/utility.cpp:2073-2089) followed by the
+    // single straight reverse step (src/hybrid_a_star.cpp:629-654)
+    DevMap &m = c->dm;
+    int k = 0;
+    m.succ_steer[k] = 0, m.succ_reverse[k] = 0, ++k;
+    if (c->P.number_of_successors > 1)
+        for (int i = 1; i <= (c->P.number_of_successors - 1) / 2; i++)
+        {
+            m.succ_steer[k] = i * deg2rad(c->P.steering_angle), m.succ_reverse[k] = 0, ++k;
+            m.succ_steer[k] = -(i * deg2rad(c->P.steering_angle)), m.succ_reverse[k] = 0, ++k;
+        }
+    if (c->P.reverse)
+        m.succ_steer[k] = 0, m.succ_reverse[k] = 1, ++k;
+    m.n_succ = k;
+    m.pen_turn = c->P.penalty_turning, m.pen_rev = c->P.penalty_reverse, m.pen_cod = c->P.penalty_change_of_direction;
+    m.shot_rho = c->P.min_turning_radius;
+    m.curve_type = c->P.curve_type;
+}
+
+int hyas_table_dims(const hyas_ctx *c, int32_t *nx, int32_t *ny, int32_t *ns)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    *nx = (int32_t)c->tab_xs.size(), *ny = (int32_t)c->tab_ys.size(), *ns = (int32_t)c->tab_ts.size();
+    return HYAS_OK;
+}
+
+int hyas_table_build_dev(hyas_ctx *c, int curve, int k0, int k1, float *out_dev)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    if (curve != HYAS_CURVE_RS)
+        return c->fail(HYAS_EINVAL, "only the Reeds-Shepp table is built on the GPU");
+    if (k0 < 0 || k1 > (int)c->tab_ts.size() || k0 > k1 || !out_dev)
+        return c->fail(HYAS_EINVAL, "slice range outside the heading loop");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    timer_begin(c);
+    launch_table_rs(c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts, (uint32_t)k0,
+                    (uint32_t)k1, (double)c->P.cd_min_turning_radius, out_dev, c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    timer_end(c, 3);
+    return HYAS_OK;
+}
+
+int hyas_table_install_dev(hyas_ctx *c, int curve, const float *raw_dev)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    if (!raw_dev)
+        return c->fail(HYAS_EINVAL, "null table");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    uint32_t *rank = nullptr;
+    HYAS_HIP(c, hipMalloc((void **)&rank, c->table_size * sizeof(uint32_t)));
+    launch_table_install(c->dm, raw_dev, c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts,
+                         (uint32_t)c->tab_ts.size(), rank, c->d_table, c->table_size, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(rank);
+    HYAS_HIP(c, e);
+    c->dm.table_miss = (curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f; // src/lookup_table.cpp:59, :85
+    c->have_table = true;
+    return HYAS_OK;
+}
+
+int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h, double res, double ox, double oy, int build_table)
+{
+    if (!c)
+        return HYAS_EINVAL;
+    if (!charmap || w == 0 || h == 0 || !(res > 0))
+        return c->fail(HYAS_EINVAL, "empty costmap or non-positive resolution");
+    if ((uint64_t)w * h >= (1u << 24))
+        return c->fail(HYAS_ERANGE, "polygon-mode indices are float arithmetic (include/node3d.h:67): w*h must stay below 2^24; "
+                                    "use hyas_set_grid for footprint-only grids");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    free_map(c);
+    c->grid_only = false;
+    c->w = w, c->h = h, c->res = res, c->ox = ox, c->oy = oy;
+    c->charmap.assign(charmap, charmap + (size_t)w * h);
+    c->twod_size = (size_t)w * h + w + 1;
+
+    DevMap &m = c->dm;
+    m = DevMap{};
+    m.w = w, m.h = h, m.res = res, m.ox = ox, m.oy = oy;
+    m.res_f = (float)res, m.ox_f = (float)ox, m.oy_f = (float)oy; // src/collisiondetection.cpp:13-15
+    m.veh_len = c->P.vehicle_length, m.veh_wid = c->P.vehicle_width;
+    m.half_wid = 0.5 * (double)c->P.vehicle_width;
+    // the on-line / on-segment snaps act within 1e-3 rad or 1e-3 m of an edge
+    // no longer than the map diagonal
+    m.cull_margin = (float)(0.01 + 2e-3 * std::sqrt((double)w * w + (double)h * h) * res);
+    m.pr = c->P.position_resolution, m.headings = c->P.headings;
+    m.delta_heading = (float)(2 * HY_PI / (double)(float)c->P.headings); // src/lookup_table.cpp:127
+    fill_motion_set(c);
+
+    // obstacles + per-key lists
+    std::vector<float> xs, ys;
+    cell_axes(c, xs, ys);
+    extract_obstacles(c, xs, ys);
+    if (c->quads.size() > 65535)
+        return c->fail(HYAS_ERANGE, "more than 65535 obstacle polygons");
+    int rc;
+    if ((rc = upload(c, c->d_charmap, c->charmap)) != HYAS_OK)
+        return rc;
+    if ((rc = upload(c, c->d_quads, c->quads)) != HYAS_OK)
+        return rc;
+    const size_t cells = (size_t)w * h;
+    c->cell_off.assign(cells + 1, 0);
+    c->cell_idx.clear();
+    if (!c->quads.empty())
+    {
+        const size_t nflag = xs.size() * ys.size() * c->quads.size();
+        float *d_xs = nullptr, *d_ys = nullptr;
+        uint8_t *d_flags = nullptr;
+        if ((rc = upload(c, d_xs, xs)) != HYAS_OK || (rc = upload(c, d_ys, ys)) != HYAS_OK)
+            return rc;
+        HYAS_HIP(c, hipMalloc((void **)&d_flags, nflag));
+        launch_in_range(c->d_quads, (uint32_t)c->quads.size(), d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(),
+                        c->P.obstacle_detection_range, d_flags, c->stream);
+        std::vector<uint8_t> flags(nflag);
+        hipError_t e = hipMemcpyAsync(flags.data(), d_flags, nflag, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_xs), (void)hipFree(d_ys), (void)hipFree(d_flags);
+        HYAS_HIP(c, e);
+        // in_range_obstacle_map_.emplace(key, list): the first loop position
+        // that maps to a key keeps it (src/collisiondetection.cpp:345)
+        std::vector<int64_t> owner(cells, -1);
+        for (size_t i = 0; i < xs.size(); ++i)
+            for (size_t j = 0; j < ys.size(); ++j)
+            {
+                uint32_t key = grid_key(m, xs[i], ys[j]);
+                if (key < cells && owner[key] < 0)
+                    owner[key] = (int64_t)(i * ys.size() + j);
+            }
+        for (size_t key = 0; key < cells; ++key)
+        {
+            c->cell_off[key] = (uint32_t)c->cell_idx.size();
+            if (owner[key] >= 0)
+            {
+                const uint8_t *f = &flags[(size_t)owner[key] * c->quads.size()];
+                for (size_t q = 0; q < c->quads.size(); ++q)
+                    if (f[q])
+                        c->cell_idx.push_back((uint16_t)q);
+            }
+        }
+        c->cell_off[cells] = (uint32_t)c->cell_idx.size();
+    }
+    if ((rc = upload(c, c->d_cell_off, c->cell_off)) != HYAS_OK || (rc = upload(c, c->d_cell_idx, c->cell_idx)) != HYAS_OK)
+        return rc;
+
+    // footprint lists
+    fpt::build(c->P, c->fp);
+    if ((rc = upload(c, c->d_fp, c->fp)) != HYAS_OK)
+        return rc;
+
+    // heuristic-table axes: the float accumulators of src/lookup_table.cpp:197-222
+    c->tab_xs.clear(), c->tab_ys.clear(), c->tab_ts.clear();
+    for (float x = 0; x < (float)(int)w; x += 1.0f / c->P.position_resolution)
+        c->tab_xs.push_back(x);
+    for (float y = 0; y < (float)(int)h; y += 1.0f / c->P.position_resolution)
+        c->tab_ys.push_back(y);
+    for (float th = 0; (double)th < 2 * HY_PI; th += m.delta_heading)
+        c->tab_ts.push_back(th);
+    if ((rc = upload(c, c->d_tab_xs, c->tab_xs)) != HYAS_OK || (rc = upload(c, c->d_tab_ys, c->tab_ys)) != HYAS_OK ||
+        (rc = upload(c, c->d_tab_ts, c->tab_ts)) != HYAS_OK)
+        return rc;
+    c->table_size = (uint64_t)(c->P.headings + 1) * w * h * c->P.position_resolution * c->P.position_resolution +
+                    (uint64_t)w * c->P.position_resolution;
+    if (c->table_size >= (1ull << 31))
+        return c->fail(HYAS_ERANGE, "heuristic table keys exceed int range (src/lookup_table.cpp:143)");
+    HYAS_HIP(c, hipMalloc((void **)&c->d_table, c->table_size * sizeof(float)));
+
+    // arc-length samples of the shot: seg after k additions of 0.1*resolution
+    // (src/ReedsShepp.cpp:566, src/hybrid_a_star.cpp:439)
+    {
+        const double step = 0.1 * (double)m.res_f;
+        const double longest = 8.0 * (std::sqrt((double)w * w + (double)h * h) * res + 2 * HY_PI * (double)c->P.min_turning_radius);
+        size_t cap = (size_t)(longest / step) + 16;
+        cap = std::min<size_t>(std::max<size_t>(cap, 1024), (size_t)1 << 22);
+        std::vector<double> seg(cap);
+        double s = 0;
+        for (size_t k = 0; k < cap; ++k, s += step)
+            seg[k] = s;
+        c->seg_cap = (uint32_t)cap;
+        if ((rc = upload(c, c->d_seg, seg)) != HYAS_OK)
+            return rc;
+    }
+
+    m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
+    m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx, m.fp = c->d_fp;
+    m.table = c->d_table, m.table_size = c->table_size;
+    m.table_miss = (c->P.curve_type == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
+    c->have_map = true;
+
+    if (build_table)
+    {
+        if (c->P.curve_type != HYAS_CURVE_RS)
+            return c->fail(HYAS_EINVAL, "Dubins heuristic table is not built on the GPU yet");
+        const size_t total = c->tab_xs.size() * c->tab_ys.size() * c->tab_ts.size();
+        float *raw = nullptr;
+        HYAS_HIP(c, hipMalloc((void **)&raw, std::max<size_t>(total, 1) * sizeof(float)));
+        rc = hyas_table_build_dev(c, HYAS_CURVE_RS, 0, (int)c->tab_ts.size(), raw);
+        if (rc == HYAS_OK)
+            rc = hyas_table_install_dev(c, HYAS_CURVE_RS, raw);
+        (void)hipFree(raw);
+        if (rc != HYAS_OK)
+            return rc;
+    }
+    return HYAS_OK;
+}
+
+// Footprint-list mode only: a bare occupancy grid of any size (no obstacle
+// polygons, no heuristic table; resolution 1, origin 0, as the footprint table
+// assumes unit cells).
+int hyas_set_grid(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h)
+{
+    if (!c)
+        return HYAS_EINVAL;
+    if (!charmap || w == 0 || h == 0)
+        return c->fail(HYAS_EINVAL, "empty grid");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    free_map(c);
+    c->w = w, c->h = h, c->res = 1, c->ox = 0, c->oy = 0;
+    c->charmap.assign(charmap, charmap + (size_t)w * h);
+    c->quads.clear(), c->cell_off.clear(), c->cell_idx.clear();
+    c->twod_size = 0;
+    DevMap &m = c->dm;
+    m = DevMap{};
+    m.w = w, m.h = h, m.res = 1, m.ox = 0, m.oy = 0, m.res_f = 1, m.ox_f = 0, m.oy_f = 0;
+    m.pr = c->P.position_resolution, m.headings = c->P.headings;
+    m.delta_heading = (float)(2 * HY_PI / (double)(float)c->P.headings);
+    int rc;
+    if ((rc = upload(c, c->d_charmap, c->charmap)) != HYAS_OK)
+        return rc;
+    fpt::build(c->P, c->fp);
+    if ((rc = upload(c, c->d_fp, c->fp)) != HYAS_OK)
+        return rc;
+    m.charmap = c->d_charmap, m.fp = c->d_fp;
+    c->have_map = true, c->have_table = false;
+    c->grid_only = true;
+    return HYAS_OK;
+}
+
+int hyas_footprint_table(hyas_ctx *c, int32_t *out, size_t cap)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    size_t n = c->fp.size() / 129;
+    if (out)
+        std::memcpy(out, c->fp.data(), std::min(cap, n) * 129 * sizeof(int32_t));
+    return (int)n;
+}
+
+int hyas_collision_batch_dev(hyas_ctx *c, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    if (mode != HYAS_MODE_POLYGON && mode != HYAS_MODE_FOOTPRINT)
+        return c->fail(HYAS_EINVAL, "unknown collision mode");
+    if (mode == HYAS_MODE_POLYGON && c->grid_only)
+        return c->fail(HYAS_ESTATE, "polygon mode needs hyas_set_costmap, not hyas_set_grid");
+    if (n == 0)
+        return HYAS_OK;
+    if (!xyt || !out)
+        return c->fail(HYAS_EINVAL, "null buffer");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    timer_begin(c);
+    launch_collision(c->dm, mode, xyt, pred_xy, n, out, c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    timer_end(c, 2);
+    return HYAS_OK;
+}
+
+int hyas_collision_batch(hyas_ctx *c, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    if (n == 0)
+        return HYAS_OK;
+    if (!xyt || !out)
+        return c->fail(HYAS_EINVAL, "null buffer");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    const size_t b_xyt = n * 3 * sizeof(float), b_pred = pred_xy ? n * 2 * sizeof(float) : 0, b_out = (n + 3) & ~(size_t)3;
+    int rc = ensure_scratch(c, b_xyt + b_pred + b_out + 64, 0);
+    if (rc != HYAS_OK)
+        return rc;
+    char *d = (char *)c->d_scratch;
+    float *d_xyt = (float *)d;
+    float *d_pred = pred_xy ? (float *)(d + b_xyt) : nullptr;
+    uint8_t *d_out = (uint8_t *)(d + b_xyt + b_pred);
+    HYAS_HIP(c, hipMemcpyAsync(d_xyt, xyt, b_xyt, hipMemcpyHostToDevice, c->stream));
+    if (pred_xy)
+        HYAS_HIP(c, hipMemcpyAsync(d_pred, pred_xy, b_pred, hipMemcpyHostToDevice, c->stream));
+    rc = hyas_collision_batch_dev(c, mode, d_xyt, d_pred, n, d_out);
+    if (rc != HYAS_OK)
+        return rc;
+    HYAS_HIP(c, hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+    return HYAS_OK;
+}
+
+int hyas_table_lookup(hyas_ctx *c, const float *xyt, size_t n, float *cost)
+{
+    if (!c || !c->have_map || !c->have_table)
+        return HYAS_ESTATE;
+    if (n == 0)
+        return HYAS_OK;
+    if (!xyt || !cost)
+        return c->fail(HYAS_EINVAL, "null buffer");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, n * 4 * sizeof(float), 0);
+    if (rc != HYAS_OK)
+        return rc;
+    float *d_xyt = (float *)c->d_scratch, *d_cost = d_xyt + 3 * n;
+    HYAS_HIP(c, hipMemcpyAsync(d_xyt, xyt, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_table_lookup(c->dm, d_xyt, n, d_cost, c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipMemcpyAsync(cost, d_cost, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    return HYAS_OK;
+}
+
+int hyas_twod_size(const hyas_ctx *c) { return (c && c->have_map) ? (int)c->twod_size : HYAS_ESTATE; }
+
+int hyas_flood(hyas_ctx *c, const hyas_goal *goal, float *out)
+{
+    if (!c || !c->have_map || c->grid_only)
+        return HYAS_ESTATE;
+    if (!goal || !out)
+        return c->fail(HYAS_EINVAL, "null buffer");
+    flood_2d(c, goal->x, goal->y, out);
+    return HYAS_OK;
+}
+
+// Shared body of hyas_expand_batch / hyas_shot_batch: one step-kernel launch
+// over n independent (node, goal) pairs.
+static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals, const float *twod, size_t n, int shoot, uint8_t *ok,
+                    float *len, hyas_succ *succ, uint8_t *count)
+{
+    if (!c || !c->have_map || !c->have_table)
+        return HYAS_ESTATE;
+    if (c->P.curve_type != HYAS_CURVE_RS)
+        return c->fail(HYAS_EINVAL, "the expansion step implements the Reeds-Shepp configuration (curve_type 1)");
+    if (n == 0)
+        return HYAS_OK;
+    if (n > 0x7fffffffu)
+        return c->fail(HYAS_ERANGE, "too many nodes in one call");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    const int K = c->dm.n_succ;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_in = take(n * sizeof(StepIn)), o_goal = take(n * sizeof(hyas_goal)), o_succ = take(n * K * sizeof(hyas_succ)),
+                 o_len = take(n * sizeof(float)), o_ok = take(n), o_cnt = take(n);
+    int rc = ensure_scratch(c, off, off);
+    if (rc != HYAS_OK)
+        return rc;
+    if (twod && (rc = ensure_twod(c, n * c->twod_size * sizeof(float))) != HYAS_OK)
+        return rc;
+    char *hs = (char *)c->h_scratch, *ds = (char *)c->d_scratch;
+    StepIn *h_in = (StepIn *)(hs + o_in);
+    for (size_t i = 0; i < n; ++i)
+        h_in[i] = StepIn{nodes[i].x, nodes[i].y, nodes[i].t, nodes[i].g, nodes[i].prim, (uint32_t)i, (uint32_t)shoot, 0};
+    std::memcpy(hs + o_goal, goals, n * sizeof(hyas_goal));
+    HYAS_HIP(c, hipMemcpyAsync(ds + o_in, hs + o_in, o_succ - o_in, hipMemcpyHostToDevice, c->stream));
+    if (twod)
+        HYAS_HIP(c, hipMemcpyAsync(c->d_twod, twod, n * c->twod_size * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HYAS_HIP(c, hipMemsetAsync(ds + o_succ, 0, off - o_succ, c->stream));
+    timer_begin(c);
+    launch_step_rs(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), twod ? c->d_twod : nullptr, c->d_seg,
+                   c->seg_cap, (uint8_t *)(ds + o_ok), (float *)(ds + o_len), (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), nullptr,
+                   c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    timer_end(c, shoot ? 0 : 1);
+    HYAS_HIP(c, hipMemcpy(hs + o_succ, ds + o_succ, off - o_succ, hipMemcpyDeviceToHost));
+    if (succ)
+        std::memcpy(succ, hs + o_succ, n * K * sizeof(hyas_succ));
+    if (count)
+        for (size_t i = 0; i < n; ++i)
+            count[i] = ((const uint8_t *)(hs + o_cnt))[i] & 15;
+    if (ok)
+        std::memcpy(ok, hs + o_ok, n);
+    if (len)
+        std::memcpy(len, hs + o_len, n * sizeof(float));
+    return HYAS_OK;
+}
+
+int hyas_expand_batch(hyas_ctx *c, const hyas_node *preds, const hyas_goal *goals, const float *twod, size_t n, hyas_succ *out, uint8_t *count)
+{
+    if (c && n && (!preds || !goals || !out || !count))
+        return c->fail(HYAS_EINVAL, "null buffer");
+    return run_step(c, preds, goals, twod, n, 0, nullptr, nullptr, out, count);
+}
+
+int hyas_shot_batch(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals, size_t n, uint8_t *ok, float *len)
+{
+    if (c && n && (!nodes || !goals || !ok || !len))
+        return c->fail(HYAS_EINVAL, "null buffer");
+    return run_step(c, nodes, goals, nullptr, n, 1, ok, len, nullptr, nullptr);
+}
+
+int hyas_plan_batch(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out)
+{
+    if (!c || !c->have_map || !c->have_table)
+        return HYAS_ESTATE;
+    if (n && (!starts || !goals || !out))
+        return c->fail(HYAS_EINVAL, "null buffer");
+    if (c->P.curve_type != HYAS_CURVE_RS)
+        return c->fail(HYAS_EINVAL, "plan_batch implements the Reeds-Shepp configuration (curve_type 1)");
+    return plan_batch_impl(c, starts, goals, n, out);
+}
+
+int hyas_get_path(const hyas_ctx *c, size_t i, float *xyt, size_t cap)
+{
+    if (!c || i >= c->paths.size())
+        return HYAS_EINVAL;
+    size_t n = c->paths[i].size() / 3;
+    if (xyt)
+        std::memcpy(xyt, c->paths[i].data(), std::min(cap, n) * 3 * sizeof(float));
+    return (int)n;
+}
+
+int hyas_get_expanded(const hyas_ctx *c, size_t i, int32_t *idx, size_t cap)
+{
+    if (!c || i >= c->expanded.size())
+        return HYAS_EINVAL;
+    size_t n = c->expanded[i].size();
+    if (idx)
+        std::memcpy(idx, c->expanded[i].data(), std::min(cap, n) * sizeof(int32_t));
+    return (int)n;
+}
+
+double hyas_last_kernel_ms(const hyas_ctx *c, int which, int64_t *launches)
+{
+    if (!c || which < 0 || which >= 5)
+        return -1;
+    if (launches)
+        *launches = c->k_launches[which];
+    return c->k_ms[which];
+}
+
+void hyas_reset_kernel_timers(hyas_ctx *c)
+{
+    if (c)
+        reset_timers(c);
+}
+
+// obstacle polygons (8 floats each) and per-key list sizes, for tests
+int hyas_get_obstacles(const hyas_ctx *c, float *out, size_t cap)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    size_t n = std::min(cap, c->quads.size());
+    for (size_t i = 0; i < n && out; ++i)
+        for (int k = 0; k < 4; ++k)
+            out[i * 8 + 2 * k] = c->quads[i].vx[k], out[i * 8 + 2 * k + 1] = c->quads[i].vy[k];
+    return (int)c->quads.size();
+}
+int hyas_in_range_count(const hyas_ctx *c, uint32_t key)
+{
+    if (!c || !c->have_map || key >= (uint64_t)c->w * c->h)
+        return -1;
+    return (int)(c->cell_off[key + 1] - c->cell_off[key]);
+}
+}

@@ -1,0 +1,566 @@
+// hyas_dev.h -- device-side data layout and the float geometry of the
+// collision path (host+device, so the map-ingest code on the host evaluates
+// the very same expressions).
+//
+// Arithmetic follows the reference expression by expression (operand order,
+// float vs double promotion); citations give the reference file:line.  All
+// elementary functions come from include/hyas_math.h; build with
+// -ffp-contract=off.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/hyas.h"
+#include "../../include/hyas_math.h"
+
+#define HD __host__ __device__ __forceinline__
+
+namespace hyas
+{
+
+struct F2
+{
+    float x, y;
+};
+HD F2 f2(float x, float y)
+{
+    F2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+HD F2 sub(F2 a, F2 b) { return f2(a.x - b.x, a.y - b.y); }
+HD F2 add(F2 a, F2 b) { return f2(a.x + b.x, a.y + b.y); }
+HD float dotf(F2 a, F2 b) { return a.x * b.x + a.y * b.y; }         // Eigen dot()
+HD float normf(F2 a) { return hy_sqrtf(a.x * a.x + a.y * a.y); }     // Eigen norm()
+HD float crossf(F2 a, F2 b) { return a.x * b.y - b.x * a.y; }        // src/utility.cpp:273-279
+HD float fmaxf_(float a, float b) { return a < b ? b : a; }          // std::max
+HD float fminf_(float a, float b) { return b < a ? b : a; }          // std::min
+
+// One obstacle quadrilateral: vertices 0..3 (vertex 4 == vertex 0 in the
+// reference's closed polygon) and its axis-aligned bounds.
+struct Quad
+{
+    float vx[4], vy[4];
+    float xmin, ymin, xmax, ymax;
+};
+HD F2 qv(const Quad &q, int i) { return f2(q.vx[i & 3], q.vy[i & 3]); }
+
+// Everything a kernel needs to know about the map and the planner settings.
+struct DevMap
+{
+    // costmap_2d state (double, as Costmap2D keeps it)
+    const uint8_t *charmap;
+    uint32_t w, h;
+    double res, ox, oy;
+    // CollisionDetection members (float)
+    float res_f, ox_f, oy_f;
+    // obstacles and per-grid-key lists (key = GetNode3DIndexOnGridMap)
+    const Quad *quads;
+    uint32_t n_quads;
+    const uint32_t *cell_off; // w*h + 1 entries
+    const uint16_t *cell_idx;
+    // vehicle
+    float veh_len, veh_wid;
+    double half_wid;     // 0.5 * vehicle_width, src/collisiondetection.cpp:626
+    float cull_margin;   // see seg_quad_may_touch()
+    // heuristic table (dense by reference key; NaN = key never emplaced)
+    const float *table;
+    uint64_t table_size;
+    float table_miss;
+    int32_t pr, headings;
+    float delta_heading; // (float)(2*M_PI/(float)headings)
+    // footprint-list mode
+    const int32_t *fp;   // entries x {len, pos[64][2]}
+    // motion set
+    int32_t n_succ;
+    float succ_steer[HYAS_MAX_SUCC];
+    int32_t succ_reverse[HYAS_MAX_SUCC];
+    float pen_turn, pen_rev, pen_cod;
+    float shot_rho; // params.min_turning_radius
+    int32_t curve_type;
+};
+
+// ---------------------------------------------------------------- Utility::
+// src/utility.cpp:1180-1185
+HD float deg2rad(float deg) { return (float)((double)(deg / 360 * 2) * HY_PI); }
+
+// src/utility.cpp:1249-1268
+HD float rad_0_2pi(float rad)
+{
+    const double two_pi = (double)2.f * HY_PI;
+    if ((double)rad >= 0 && (double)rad < two_pi)
+        return rad;
+    float out = (float)hy_fmod((double)rad, two_pi);
+    if (out < 0)
+        out = (float)((double)out + two_pi);
+    if (hy_fabs((double)out - 2 * HY_PI) < 1e-3)
+        out = 0;
+    return out;
+}
+
+// src/utility.cpp:1210-1231
+HD float rad_norm(float rad)
+{
+    if ((double)rad >= -HY_PI && (double)rad <= HY_PI)
+        return rad;
+    const double two_pi = (double)2.f * HY_PI;
+    float out = (float)hy_fmod((double)rad, two_pi);
+    if (out < 0)
+        out = (float)((double)out + two_pi);
+    if ((double)out > HY_PI)
+        out = (float)((double)out - (double)2.0f * HY_PI);
+    if ((double)hy_fabsf(out) < 1e-6)
+        out = 0;
+    return out;
+}
+
+// src/utility.cpp:209-249: is q on segment [a, b]?
+HD bool on_segment(F2 a, F2 b, F2 q)
+{
+    const bool in_y = q.y <= fmaxf_(a.y, b.y) && q.y >= fminf_(a.y, b.y);
+    const bool in_x = q.x <= fmaxf_(a.x, b.x) && q.x >= fminf_(a.x, b.x);
+    if ((double)hy_fabsf(q.x - a.x) < 1e-3 && (double)hy_fabsf(q.x - b.x) < 1e-3 && in_y)
+        return true;
+    if (in_x && (double)hy_fabsf(q.y - a.y) < 1e-3 && (double)hy_fabsf(q.y - b.y) < 1e-3)
+        return true;
+    if (in_x && in_y)
+    {
+        F2 aq = sub(q, a), ab = sub(b, a);
+        return (double)hy_fabsf(dotf(aq, ab) / normf(aq) / normf(ab) - 1) < 1e-6;
+    }
+    return false;
+}
+
+// src/utility.cpp:251-271
+HD bool point_on_line(F2 p, F2 start, F2 unit)
+{
+    F2 d = sub(p, start);
+    if ((double)hy_fabsf(d.x) < 1e-3 && (double)hy_fabsf(d.y) < 1e-3)
+        return true;
+    float angle = hy_acosf(dotf(d, unit) / normf(d) / normf(unit));
+    return (double)hy_fabsf(angle) < 1e-3 || hy_fabs((double)angle - HY_PI) < 1e-3;
+}
+
+// src/utility.cpp:280-306
+HD bool seg_intersect(F2 p1, F2 p2, F2 p3, F2 p4)
+{
+    if ((p1.x == p2.x && p2.x == p3.x && p3.x == p4.x) || (p1.y == p2.y && p2.y == p3.y && p3.y == p4.y))
+        return false;
+    if (fmaxf_(p3.x, p4.x) < fminf_(p1.x, p2.x) || fmaxf_(p3.y, p4.y) < fminf_(p1.y, p2.y) ||
+        fmaxf_(p1.x, p2.x) < fminf_(p3.x, p4.x) || fmaxf_(p1.y, p2.y) < fminf_(p3.y, p4.y))
+        return false;
+    F2 d43 = sub(p4, p3), d12 = sub(p1, p2);
+    return crossf(sub(p1, p3), d43) * crossf(sub(p2, p3), d43) <= 0 &&
+           crossf(sub(p3, p2), d12) * crossf(sub(p4, p2), d12) <= 0;
+}
+
+// src/utility.cpp:308-327 (caller has already established intersection)
+HD F2 intersection_point(F2 p1, F2 p2, F2 p3, F2 p4)
+{
+    F2 d1 = sub(p2, p1), d2 = sub(p4, p3);
+    float t = crossf(sub(p3, p1), d2) / crossf(d1, d2);
+    return add(p1, f2(t * d1.x, t * d1.y));
+}
+
+// src/utility.cpp:328-374, returns 1 for above/on, 0 for below
+HD int above_segment(F2 p1, F2 p2, F2 p3)
+{
+    if (on_segment(p1, p2, p3))
+        return 1;
+    F2 d = sub(p2, p1);
+    if (d.x == 0)
+        return p3.x > p1.x ? 0 : 1;
+    if (d.y == 0)
+        return p3.y > p1.y ? 1 : 0;
+    float k = d.y / d.x;
+    float b = p1.y - k * p1.x;
+    return (k * p3.x + b - p3.y < 0) ? 1 : 0;
+}
+
+// src/utility.cpp:375-422: ray casting towards (10000, p.y)
+HD bool inside_quad(const Quad &q, F2 p)
+{
+    F2 far_pt = f2(10000, p.y);
+    int crossings = 0;
+    for (int i = 0; i < 4; ++i)
+    {
+        F2 a = qv(q, i), b = qv(q, i + 1);
+        if (seg_intersect(p, far_pt, a, b))
+        {
+            F2 ip = intersection_point(p, far_pt, a, b);
+            if ((double)normf(sub(a, ip)) < 1e-3)
+                crossings += (above_segment(p, far_pt, b) == 0);
+            else if ((double)normf(sub(b, ip)) < 1e-3)
+                crossings += (above_segment(p, far_pt, a) == 0);
+            else
+                crossings += 1;
+        }
+    }
+    return (crossings & 1) != 0;
+}
+
+// src/utility.cpp:1591-1596: Eigen normalized()
+HD F2 unit_vector(F2 a, F2 b)
+{
+    F2 d = sub(b, a);
+    float z = d.x * d.x + d.y * d.y;
+    if (z > 0)
+    {
+        float n = hy_sqrtf(z);
+        return f2(d.x / n, d.y / n);
+    }
+    return d;
+}
+
+// src/utility.cpp:578-592
+HD float dist_point_line(F2 p, F2 start, F2 unit)
+{
+    if (point_on_line(p, start, unit))
+        return 0;
+    F2 d = sub(p, start);
+    float proj = hy_fabsf(dotf(d, unit));
+    float n = normf(d);
+    return hy_sqrtf(n * n - proj * proj);
+}
+
+// src/utility.cpp:541-576
+HD float dist_seg_point(F2 a, F2 b, F2 p)
+{
+    if (on_segment(a, b, p))
+        return 0;
+    F2 unit = unit_vector(a, b);
+    float da = normf(sub(a, p)), db = normf(sub(b, p));
+    F2 far_pt = da > db ? a : b;
+    F2 ab = sub(b, a);
+    float len = normf(ab);
+    float proj = hy_fabsf(dotf(sub(p, far_pt), ab)) / len;
+    if (proj > len)
+        return fminf_(da, db);
+    return dist_point_line(p, a, unit);
+}
+
+// src/utility.cpp:594-619
+HD float dist_quad_point(const Quad &q, F2 p)
+{
+    for (int i = 0; i < 4; ++i)
+        if (on_segment(qv(q, i), qv(q, i + 1), p))
+            return 0;
+    if (inside_quad(q, p))
+        return -1;
+    float best = 100000;
+    for (int i = 0; i < 4; ++i)
+    {
+        float d = dist_seg_point(qv(q, i), qv(q, i + 1), p);
+        if (d < best)
+            best = d;
+    }
+    return best;
+}
+
+// src/utility.cpp:967-997
+HD float dist_quad_segment(const Quad &q, F2 s, F2 e)
+{
+    for (int i = 0; i < 4; ++i)
+        if (seg_intersect(qv(q, i), qv(q, i + 1), s, e))
+            return -1;
+    float out = 100000;
+    float d = dist_quad_point(q, s);
+    if (out > d)
+        out = d;
+    d = dist_quad_point(q, e);
+    if (out > d)
+        out = d;
+    for (int i = 0; i < 5; ++i)
+    {
+        d = dist_seg_point(s, e, qv(q, i));
+        if (out > d)
+            out = d;
+    }
+    return out;
+}
+
+// ------------------------------------------------------- costmap / indices
+// costmap_2d::Costmap2D::worldToMap (ROS dependency, restated: reject below the
+// origin, truncate (w - origin)/resolution, accept iff inside the size).
+HD bool world_to_map(const DevMap &m, float wx, float wy, uint32_t &mx, uint32_t &my)
+{
+    double x = (double)wx, y = (double)wy;
+    if (x < m.ox || y < m.oy)
+        return false;
+    mx = (uint32_t)(int)((x - m.ox) / m.res);
+    my = (uint32_t)(int)((y - m.oy) / m.res);
+    return mx < m.w && my < m.h;
+}
+HD bool on_grid(const DevMap &m, float x, float y)
+{
+    uint32_t a, b;
+    return world_to_map(m, x, y, a, b);
+}
+
+// floor(round(v*1000)/1000), the index rounding of include/node3d.h:67
+HD float idx_round(float v) { return hy_floorf(hy_roundf(v * 1000) / 1000); }
+
+// src/collisiondetection.cpp:362-369
+HD uint32_t grid_key(const DevMap &m, float x, float y)
+{
+    return (uint32_t)(idx_round((y - m.oy_f) / m.res_f) * m.w + idx_round((x - m.ox_f) / m.res_f));
+}
+// include/node2d.h:59-66
+HD int idx_2d(const DevMap &m, float x, float y)
+{
+    return (int)(idx_round((y - m.oy_f) / m.res_f) * (int)m.w + idx_round((x - m.ox_f) / m.res_f));
+}
+// include/node3d.h:65-72 with delta = (float)((float)2*M_PI/headings)
+HD int idx_3d(const DevMap &m, float x, float y, float t)
+{
+    const float delta = (float)((double)(float)2 * HY_PI / m.headings);
+    return (int)(idx_round(t / delta) * (int)m.w * (int)m.h + idx_round((y - m.oy_f) / m.res_f) * (int)m.w +
+                 idx_round((x - m.ox_f) / m.res_f));
+}
+
+// -------------------------------------------------- collision, polygon mode
+// src/utility.cpp:476-510: corners of the vehicle rectangle at (x, y, t)
+HD void vehicle_corners(const DevMap &m, float x, float y, float t, F2 c[4])
+{
+    const float w = m.veh_len, h = m.veh_wid; // CreatePolygon(center, vehicle_length, vehicle_width, t)
+    const float ct = hy_cosf(t), st = hy_sinf(t);
+    const float m01 = -st;
+    const float px[4] = {-w / 2, +w / 2, +w / 2, -w / 2};
+    const float py[4] = {-h / 2, -h / 2, +h / 2, +h / 2};
+    for (int i = 0; i < 4; ++i)
+        c[i] = f2(x + (ct * px[i] + m01 * py[i]), y + (st * px[i] + ct * py[i]));
+}
+
+// src/utility.cpp:956-966 + :528-540 for a 4-corner vehicle against one quad.
+// The bounding-box test is exact: when the boxes are strictly apart every
+// edge pair fails IsIntersect's own box test.
+HD bool vehicle_hits_quad(const F2 c[4], float bxmin, float bymin, float bxmax, float bymax, const Quad &q)
+{
+    if (q.xmax < bxmin || q.ymax < bymin || bxmax < q.xmin || bymax < q.ymin)
+        return false;
+    for (int i = 0; i < 4; ++i)
+    {
+        F2 a = c[i], b = c[(i + 1) & 3];
+        for (int j = 0; j < 4; ++j)
+            if (seg_intersect(qv(q, j), qv(q, j + 1), a, b))
+                return true;
+    }
+    return false;
+}
+
+// src/collisiondetection.cpp:189-214 + :573-606.  true = free.
+HD bool pose_free(const DevMap &m, float x, float y, float t)
+{
+    uint32_t sx, sy;
+    if (!world_to_map(m, x, y, sx, sy))
+        return false;
+    if (m.charmap[sx + sy * m.w] >= 250)
+        return false;
+    F2 c[4];
+    vehicle_corners(m, x, y, t, c);
+    float bxmin = c[0].x, bxmax = c[0].x, bymin = c[0].y, bymax = c[0].y;
+    for (int i = 0; i < 4; ++i)
+    {
+        if (!on_grid(m, c[i].x, c[i].y))
+            return false;
+        bxmin = fminf_(bxmin, c[i].x), bxmax = fmaxf_(bxmax, c[i].x);
+        bymin = fminf_(bymin, c[i].y), bymax = fmaxf_(bymax, c[i].y);
+    }
+    uint32_t key = grid_key(m, c[0].x, c[0].y);
+    if (key >= m.w * m.h)
+        return true; // key absent from in_range_obstacle_map_: nothing to test
+    for (uint32_t k = m.cell_off[key], e = m.cell_off[key + 1]; k < e; ++k)
+        if (vehicle_hits_quad(c, bxmin, bymin, bxmax, bymax, m.quads[m.cell_idx[k]]))
+            return false;
+    return true;
+}
+
+// Can GetDistanceFromPolygonToSegment(q, s, e) come out <= half_wid?  Every
+// candidate it takes the minimum over is a point-to-segment distance between
+// the two shapes, except that IsPointOnLine/OnSegment snap distances below
+// about 1e-3 x (edge length) to zero; cull_margin (set by the host from the
+// map diagonal) covers that snap, so a box gap above half_wid + margin proves
+// the test cannot fire.
+HD bool seg_quad_may_touch(const DevMap &m, F2 s, F2 e, const Quad &q)
+{
+    const float r = (float)m.half_wid + m.cull_margin;
+    float sxmin = fminf_(s.x, e.x) - r, sxmax = fmaxf_(s.x, e.x) + r;
+    float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
+    return !(q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin);
+}
+
+// src/collisiondetection.cpp:608-656.  true = free.
+HD bool segment_free(const DevMap &m, float sx, float sy, float ex, float ey)
+{
+    if (!on_grid(m, sx, sy) || !on_grid(m, ex, ey))
+        return false;
+    F2 s = f2(sx, sy), e = f2(ex, ey);
+    uint32_t ks = grid_key(m, sx, sy), ke = grid_key(m, ex, ey);
+    const uint32_t cells = m.w * m.h;
+    if (ks < cells)
+        for (uint32_t k = m.cell_off[ks], end = m.cell_off[ks + 1]; k < end; ++k)
+        {
+            const Quad &q = m.quads[m.cell_idx[k]];
+            if (seg_quad_may_touch(m, s, e, q) && (double)dist_quad_segment(q, s, e) <= m.half_wid)
+                return false;
+        }
+    if (ke < cells && ke != ks) // same key: same list, same verdicts
+        for (uint32_t k = m.cell_off[ke], end = m.cell_off[ke + 1]; k < end; ++k)
+        {
+            const Quad &q = m.quads[m.cell_idx[k]];
+            if (seg_quad_may_touch(m, s, e, q) && (double)dist_quad_segment(q, s, e) <= m.half_wid)
+                return false;
+        }
+    return true;
+}
+
+// src/collisiondetection.cpp:93-127
+HD bool traversable(const DevMap &m, float x, float y, float t, bool has_pred, float px, float py)
+{
+    if (!on_grid(m, x, y))
+        return false;
+    if (!pose_free(m, x, y, t))
+        return false;
+    return has_pred ? segment_free(m, x, y, px, py) : true;
+}
+
+// ------------------------------------------------ collision, footprint mode
+// Pose test over the per-heading footprint cell list (table layout of
+// include/constants.h:62-80, built by include/lookup.h:30-284): truncate the
+// pose to its cell, sub-cell bin and heading bin, then every listed cell must
+// be on the grid and below the lethal threshold (>= 250 collides, as in
+// src/collisiondetection.cpp:200).
+HD bool footprint_free(const DevMap &m, float x, float y, float t)
+{
+    const int pr = m.pr;
+    int X = (int)x, Y = (int)y;
+    int iX = (int)((x - (long)x) * pr);
+    iX = iX > 0 ? iX : 0;
+    int iY = (int)((y - (long)y) * pr);
+    iY = iY > 0 ? iY : 0;
+    int iT = (int)(t / m.delta_heading);
+    if (iT < 0 || iT >= m.headings || iX >= pr || iY >= pr)
+        return false;
+    const int32_t *e = m.fp + (size_t)((iY * pr + iX) * m.headings + iT) * 129;
+    int n = e[0] < 64 ? e[0] : 64;
+    for (int i = 0; i < n; ++i)
+    {
+        int cX = X + e[1 + 2 * i], cY = Y + e[2 + 2 * i];
+        if (cX < 0 || (uint32_t)cX >= m.w || cY < 0 || (uint32_t)cY >= m.h)
+            return false;
+        if (m.charmap[(size_t)cY * m.w + cX] >= 250)
+            return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------- heuristic lookups
+// src/lookup_table.cpp:123-146
+HD int table_key(const DevMap &m, float x, float y, float theta)
+{
+    float angle = ((double)hy_fabsf(theta) < 1e-4) ? 0 : theta;
+    int x_index = (int)(x * m.pr);
+    int y_index = (int)(y * m.pr);
+    return (int)(angle / m.delta_heading) * (int)m.w * (int)m.h * m.pr * m.pr + (int)(y_index * m.pr) * (int)m.w + x_index;
+}
+// src/lookup_table.cpp:56-96, :113-122
+HD float table_cost(const DevMap &m, float x, float y, float t)
+{
+    int key = table_key(m, x, y, rad_0_2pi(t));
+    if (key >= 0 && (uint64_t)key < m.table_size)
+    {
+        float v = m.table[key];
+        if (v == v)
+            return v;
+    }
+    return m.table_miss;
+}
+// src/hybrid_a_star.cpp:316-366; twod = this goal's 2D cost map (-1 = absent) or null
+HD float heuristic(const DevMap &m, float x, float y, float t, float gx, float gy, float gt, const float *twod)
+{
+    float curve = table_cost(m, hy_fabsf(gx - x), hy_fabsf(gy - y), gt - t);
+    float two_d = 0;
+    if (twod)
+    {
+        int id = idx_2d(m, x, y);
+        if (id >= 0 && id < (int)(m.w * m.h))
+        {
+            float v = twod[id];
+            if (v >= 0)
+                two_d = v;
+        }
+    }
+    return fmaxf_(curve, two_d);
+}
+
+// ------------------------------------------------------------- successors
+// src/hybrid_a_star.cpp:659-756 for motion-set entry k of node (x,y,t).
+// Returns false when the step is too small to create a successor (:681).
+HD bool successor_pose(const DevMap &m, float x, float y, float t, float dist_to_goal, int k, float &sx, float &sy, float &st,
+                       int &prim)
+{
+    const bool rev = m.succ_reverse[k] != 0;
+    // :606-614, :634-642
+    float first;
+    if (!rev)
+    {
+        float step = 0.2f;
+        first = (step > dist_to_goal) ? dist_to_goal : step;
+    }
+    else
+    {
+        float step = -0.2f;
+        first = (hy_fabsf(step) > dist_to_goal) ? -dist_to_goal : step;
+    }
+    const bool reverse_flag = first < 0;
+    if ((double)hy_fabsf(first) <= 1e-3)
+        return false;
+    const float steer = m.succ_steer[k];
+    const float radius = first / hy_fabsf(steer);
+    float dx, dy;
+    if (steer < 0)
+    {
+        dx = radius * hy_sinf(hy_fabsf(steer));
+        dy = -(radius * (1 - hy_cosf(steer)));
+        prim = reverse_flag ? 4 : 1;
+    }
+    else if ((double)steer > 1e-3)
+    {
+        dx = radius * hy_sinf(hy_fabsf(steer));
+        dy = (radius * (1 - hy_cosf(steer)));
+        prim = reverse_flag ? 5 : 2;
+    }
+    else
+    {
+        dx = first;
+        dy = 0;
+        prim = reverse_flag ? 3 : 0;
+    }
+    const float ct = hy_cosf(t), sn = hy_sinf(t);
+    sx = x + dx * ct - dy * sn;
+    sy = y + dx * sn + dy * ct;
+    st = rad_0_2pi(t + steer);
+    return true;
+}
+
+// src/hybrid_a_star.cpp:761-811
+HD float cost_so_far(const DevMap &m, float g, float step, int prim, int pre_prim)
+{
+    if (prim < 3)
+    {
+        if (pre_prim != prim)
+            g += (pre_prim > 2) ? step * m.pen_turn * m.pen_cod : step * m.pen_turn;
+        else
+            g += step;
+    }
+    else
+    {
+        if (pre_prim != prim)
+            g += (pre_prim < 3) ? step * m.pen_turn * m.pen_rev * m.pen_cod : step * m.pen_turn * m.pen_rev;
+        else
+            g += step * m.pen_rev;
+    }
+    return g;
+}
+
+} // namespace hyas

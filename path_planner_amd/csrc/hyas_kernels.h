@@ -1,0 +1,34 @@
+// hyas_kernels.h -- launch wrappers of hyas_kernels.hip (device pointers only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hyas_dev.h"
+
+namespace hyas
+{
+
+// One popped node handed to the expansion step.
+struct StepIn
+{
+    float x, y, t, g;
+    int32_t prim;
+    uint32_t query; // which goal / 2D cost map
+    uint32_t shoot; // 1: evaluate the analytic shot for this node
+    uint32_t pad;
+};
+
+void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
+void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
+                     uint8_t *flags, hipStream_t s);
+void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,
+                     float *out, hipStream_t s);
+void launch_table_install(const DevMap &m, const float *raw, const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts,
+                          uint32_t ns, uint32_t *rank, float *table, uint64_t table_size, hipStream_t s);
+void launch_table_lookup(const DevMap &m, const float *xyt, size_t n, float *cost, hipStream_t s);
+void launch_step_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
+                    uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
+                    hipStream_t s);
+void launch_shot_path(const DevMap &m, const StepIn &node, const hyas_goal &goal, const double *seg_tab, uint32_t seg_cap, float *out,
+                      uint32_t out_cap, uint32_t *n_out, hipStream_t s);
+
+} // namespace hyas

@@ -1,0 +1,438 @@
+// hyas_kernels.hip -- gfx950 kernels of the Hybrid A* expansion path and their
+// launch wrappers.  Build: hipcc --offload-arch=gfx950 -ffp-contract=off.
+//
+// None of this is a dense contraction, so there is no MFMA here.  The map
+// (char grid, obstacle quads, per-key lists, heuristic table) is read-only and
+// small, so it lives in L2/L1 after first touch; the kernels are organised so
+// that lanes of a wave walk the same per-key obstacle list (neighbouring
+// samples of one curve, successors of one node) and leave together through a
+// ballot as soon as any lane reports a collision.
+#include <hip/hip_runtime.h>
+
+#include "hyas_dev.h"
+#include "hyas_kernels.h"
+#include "hyas_rs.h"
+
+namespace hyas
+{
+
+// ------------------------------------------------------------------ collision
+__global__ void __launch_bounds__(256) k_collision_polygon(DevMap m, const float *__restrict__ xyt,
+                                                           const float *__restrict__ pred_xy, size_t n,
+                                                           uint8_t *__restrict__ out)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        float x = xyt[3 * i], y = xyt[3 * i + 1], t = xyt[3 * i + 2];
+        bool ok = pred_xy ? traversable(m, x, y, t, true, pred_xy[2 * i], pred_xy[2 * i + 1]) : traversable(m, x, y, t, false, 0, 0);
+        out[i] = ok ? 1 : 0;
+    }
+}
+
+// Footprint-list mode: 4 poses per thread so the verdict store is one dword.
+__global__ void __launch_bounds__(256) k_collision_footprint(DevMap m, const float *__restrict__ xyt, size_t n,
+                                                             uint8_t *__restrict__ out)
+{
+    const size_t groups = (n + 3) / 4;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x)
+    {
+        const size_t i0 = g * 4;
+        if (i0 + 4 <= n)
+        {
+            // 48 contiguous bytes per thread: three 16-byte loads
+            const float4 *p = reinterpret_cast<const float4 *>(xyt + 3 * i0);
+            float4 a = p[0], b = p[1], c = p[2];
+            uint32_t v = 0;
+            v |= footprint_free(m, a.x, a.y, a.z) ? 1u : 0u;
+            v |= footprint_free(m, a.w, b.x, b.y) ? 1u << 8 : 0u;
+            v |= footprint_free(m, b.z, b.w, c.x) ? 1u << 16 : 0u;
+            v |= footprint_free(m, c.y, c.z, c.w) ? 1u << 24 : 0u;
+            *reinterpret_cast<uint32_t *>(out + i0) = v;
+        }
+        else
+        {
+            for (size_t i = i0; i < n; ++i)
+                out[i] = footprint_free(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]) ? 1 : 0;
+        }
+    }
+}
+
+// --------------------------------------------------------------- map ingest
+// flags[c * n_quads + q] = 1 iff quad q is within `range` of the cell corner
+// (xs[c / nys], ys[c % nys]): the test of src/collisiondetection.cpp:335-343.
+__global__ void __launch_bounds__(256) k_in_range(const Quad *__restrict__ quads, uint32_t n_quads,
+                                                  const float *__restrict__ xs, uint32_t nxs,
+                                                  const float *__restrict__ ys, uint32_t nys, float range,
+                                                  uint8_t *__restrict__ flags)
+{
+    const size_t total = (size_t)nxs * nys * n_quads;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    {
+        uint32_t q = (uint32_t)(i % n_quads);
+        size_t c = i / n_quads;
+        F2 p = f2(xs[c / nys], ys[c % nys]);
+        flags[i] = dist_quad_point(quads[q], p) < range ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------ heuristic table
+// One table entry per thread (src/lookup_table.cpp:209-218): cost of the
+// Reeds-Shepp path from the origin to (xs[i], ys[j], ts[k]).
+__global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, uint32_t nx,
+                                                  const float *__restrict__ ys, uint32_t ny,
+                                                  const float *__restrict__ ts, uint32_t k0, uint32_t k1, double rho,
+                                                  float *__restrict__ out)
+{
+    const size_t total = (size_t)(k1 - k0) * ny * nx;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    {
+        uint32_t i = (uint32_t)(e % nx);
+        uint32_t j = (uint32_t)((e / nx) % ny);
+        uint32_t k = k0 + (uint32_t)(e / ((size_t)nx * ny));
+        const double q0[3] = {0, 0, 0};
+        const double q1[3] = {(double)xs[i], (double)ys[j], (double)ts[k]};
+        double x, y, phi;
+        rs::normalise(q0, q1, rho, x, y, phi);
+        out[e] = (float)(rho * rs::solve_serial(x, y, phi).total);
+    }
+}
+
+// First-write-wins emplace (src/lookup_table.cpp:215) in two passes: pass 0
+// records for every key the earliest loop position (x outer, y, theta inner)
+// that maps to it, pass 1 lets exactly that position store its cost.
+__global__ void __launch_bounds__(256) k_table_install(DevMap m, const float *__restrict__ raw,
+                                                       const float *__restrict__ xs, uint32_t nx,
+                                                       const float *__restrict__ ys, uint32_t ny,
+                                                       const float *__restrict__ ts, uint32_t ns,
+                                                       uint32_t *__restrict__ rank, float *__restrict__ table,
+                                                       uint64_t table_size, int pass)
+{
+    const size_t total = (size_t)ns * ny * nx;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    {
+        uint32_t i = (uint32_t)(e % nx);
+        uint32_t j = (uint32_t)((e / nx) % ny);
+        uint32_t k = (uint32_t)(e / ((size_t)nx * ny));
+        if (xs[i] == 0 && ys[j] == 0)
+            continue; // :204-208
+        int key = table_key(m, xs[i], ys[j], ts[k]);
+        if (key < 0 || (uint64_t)key >= table_size)
+            continue;
+        uint32_t order = (i * ny + j) * ns + k;
+        if (pass == 0)
+            atomicMin(&rank[key], order);
+        else if (rank[key] == order)
+            table[key] = raw[e];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_table_lookup(DevMap m, const float *__restrict__ xyt, size_t n,
+                                                      float *__restrict__ cost)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        cost[i] = table_cost(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]);
+}
+
+__global__ void __launch_bounds__(256) k_fill_u32(uint32_t *p, size_t n, uint32_t v)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+// ------------------------------------------------------------- expansion step
+__device__ __forceinline__ double wave_min(double v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        double o = __shfl_xor(v, off, 64);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+// Lanes 0..43 of one wave evaluate one Reeds-Shepp candidate each; the five
+// families are then reduced in reference order.  Every lane returns the path.
+__device__ __forceinline__ rs::Path solve_wave(double x, double y, double phi, int lane)
+{
+    rs::Path mine;
+    double L = 0;
+    bool valid = false;
+    if (lane < RS_NUM_CANDIDATES)
+        valid = rs::candidate(lane, x, y, phi, mine, L);
+    const double inf = __builtin_huge_val();
+    rs::Path best = rs::empty_path();
+    for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
+    {
+        const bool in_fam = lane >= rs::family_first(fam) && lane < rs::family_first(fam + 1);
+        const double key = (valid && in_fam && L == L) ? L : inf;
+        const double mn = wave_min(key);
+        const double bound = rs::family_bound(fam, best.total);
+        if (bound > mn) // uniform across the wave
+        {
+            unsigned long long who = __ballot(key == mn);
+            int src = __ffsll((long long)who) - 1;
+            best.type = __shfl(mine.type, src, 64);
+            for (int i = 0; i < 5; ++i)
+                best.len[i] = __shfl(mine.len[i], src, 64);
+            best.total = __shfl(mine.total, src, 64);
+        }
+    }
+    return best;
+}
+
+// Number of samples the loop `for (seg = 0; seg <= length; seg += step)`
+// produces (src/ReedsShepp.cpp:566): seg_tab[k] holds seg after k additions.
+__device__ __forceinline__ uint32_t count_samples(const double *__restrict__ seg_tab, uint32_t cap, double length)
+{
+    uint32_t lo = 0, hi = cap; // first k with seg_tab[k] > length
+    while (lo < hi)
+    {
+        uint32_t mid = (lo + hi) >> 1;
+        if (seg_tab[mid] <= length)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+#define STEP_THREADS 256
+
+// One workgroup per popped node.  Wave 1 generates the motion-primitive
+// successors with verdict, g, h and index (src/hybrid_a_star.cpp:540-811,
+// :316-366); wave 0 solves the Reeds-Shepp shot to the goal; then all four
+// waves sample the curve (:429-468) until a sample collides.
+__global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
+                                                          const hyas_goal *__restrict__ goals,
+                                                          const float *__restrict__ twod, // [query][w*h] or null
+                                                          const double *__restrict__ seg_tab, uint32_t seg_cap,
+                                                          uint8_t *__restrict__ shot_ok,
+                                                          float *__restrict__ shot_len, uint8_t *__restrict__ count,
+                                                          hyas_succ *__restrict__ succ, unsigned long long *stats)
+{
+    __shared__ rs::Path s_path;
+    __shared__ float s_xy[STEP_THREADS][2];
+    __shared__ int s_hit;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const StepIn node = in[slot];
+    const bool do_shot = node.shoot != 0; // uniform across the workgroup
+    const hyas_goal goal = goals[node.query];
+    const float *my_twod = twod ? twod + (size_t)node.query * m.w * m.h : nullptr;
+
+    if (wave == 0)
+    {
+        if (do_shot)
+        {
+            const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
+            const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
+            double x, y, phi;
+            rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
+            rs::Path p = solve_wave(x, y, phi, lane);
+            if (lane == 0)
+                s_path = p;
+        }
+        if (lane == 0)
+            s_hit = 0;
+    }
+    else if (wave == 1)
+    {
+        const int K = m.n_succ;
+        bool ok = false, evaluated = false;
+        hyas_succ s;
+        if (lane < K)
+        {
+            float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
+            float sx, sy, st;
+            int prim;
+            if (successor_pose(m, node.x, node.y, node.t, dist, lane, sx, sy, st, prim))
+            {
+                evaluated = true;
+                ok = traversable(m, sx, sy, st, true, node.x, node.y);
+                if (ok)
+                {
+                    float step = normf(sub(f2(sx, sy), f2(node.x, node.y)));
+                    s.x = sx, s.y = sy, s.t = st;
+                    s.g = cost_so_far(m, node.g, step, prim, node.prim);
+                    s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
+                    s.idx = idx_3d(m, sx, sy, st);
+                    s.prim = (int8_t)prim;
+                    s.free = 1;
+                    s.pad = 0;
+                }
+            }
+        }
+        // compact in motion-set order, as the reference's output vector
+        unsigned long long mask = __ballot(ok);
+        unsigned long long emask = __ballot(evaluated);
+        if (ok)
+        {
+            int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            succ[(size_t)slot * m.n_succ + pos] = s;
+        }
+        if (lane == 0) // low nibble: emitted successors, high nibble: candidates that got a verdict
+            count[slot] = (uint8_t)(__popcll(mask) | (__popcll(emask) << 4));
+    }
+    if (!do_shot)
+    {
+        if (tid == 0)
+            shot_ok[slot] = 0, shot_len[slot] = 0;
+        return;
+    }
+    __syncthreads();
+
+    const rs::Path path = s_path;
+    const double rho = (double)m.shot_rho;
+    const double length = rho * path.total; // :564
+    const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
+    const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
+    float prev_x = node.x, prev_y = node.y; // predecessor of sample 0 is the node itself
+    bool collided = false;
+    unsigned long long tested = 0;
+    for (uint32_t base = 0; base < nsamp; base += STEP_THREADS)
+    {
+        const uint32_t k = base + tid;
+        float x = 0, y = 0, t = 0;
+        if (k < nsamp)
+        {
+            double s[3];
+            rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
+            x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+        }
+        s_xy[tid][0] = x, s_xy[tid][1] = y;
+        __syncthreads();
+        bool hit = false;
+        if (k < nsamp)
+        {
+            float px = tid ? s_xy[tid - 1][0] : prev_x, py = tid ? s_xy[tid - 1][1] : prev_y;
+            hit = !traversable(m, x, y, t, true, px, py);
+            ++tested;
+        }
+        prev_x = s_xy[STEP_THREADS - 1][0], prev_y = s_xy[STEP_THREADS - 1][1];
+        if (hit)
+            s_hit = 1;
+        __syncthreads();
+        if (s_hit)
+        {
+            collided = true;
+            break;
+        }
+    }
+    if (tid == 0)
+    {
+        // an empty sample list is "no shot" (path_vec.size() == 0, :524)
+        shot_ok[slot] = (!collided && nsamp > 0) ? 1 : 0;
+        shot_len[slot] = (float)length;
+    }
+    if (stats && tested)
+        atomicAdd(stats, tested);
+}
+
+// Writes the accepted curve of one query: n samples {x, y, t} (+ the caller
+// appends the goal, :526).
+__global__ void __launch_bounds__(256) k_shot_path(DevMap m, StepIn node, hyas_goal goal,
+                                                   const double *__restrict__ seg_tab, uint32_t seg_cap,
+                                                   float *__restrict__ out, uint32_t out_cap, uint32_t *n_out)
+{
+    __shared__ rs::Path s_path;
+    const int tid = threadIdx.x;
+    const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
+    const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
+    const double rho = (double)m.shot_rho;
+    if (tid < 64)
+    {
+        double x, y, phi;
+        rs::normalise(q0, q1, rho, x, y, phi);
+        rs::Path p = solve_wave(x, y, phi, tid);
+        if (tid == 0)
+            s_path = p;
+    }
+    __syncthreads();
+    const rs::Path path = s_path;
+    const double length = rho * path.total;
+    const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
+    if (tid == 0)
+        *n_out = nsamp;
+    for (uint32_t k = tid; k < nsamp && k < out_cap; k += blockDim.x)
+    {
+        double s[3];
+        rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
+        out[3 * k] = (float)s[0], out[3 * k + 1] = (float)s[1], out[3 * k + 2] = rad_0_2pi((float)s[2]);
+    }
+}
+
+// ------------------------------------------------------------ launch wrappers
+static inline int grid_for(size_t n, int block = 256, int cap = 256 * 8)
+{
+    size_t g = (n + block - 1) / block;
+    if (g < 1)
+        g = 1;
+    return (int)(g > (size_t)cap ? cap : g);
+}
+
+void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s)
+{
+    if (n == 0)
+        return;
+    if (mode == HYAS_MODE_FOOTPRINT)
+        hipLaunchKernelGGL(k_collision_footprint, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, m, xyt, n, out);
+    else
+        hipLaunchKernelGGL(k_collision_polygon, dim3(grid_for(n)), dim3(256), 0, s, m, xyt, pred_xy, n, out);
+}
+
+void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
+                     uint8_t *flags, hipStream_t s)
+{
+    size_t total = (size_t)nxs * nys * n_quads;
+    if (total == 0)
+        return;
+    hipLaunchKernelGGL(k_in_range, dim3(grid_for(total)), dim3(256), 0, s, quads, n_quads, xs, nxs, ys, nys, range, flags);
+}
+
+void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,
+                     float *out, hipStream_t s)
+{
+    size_t total = (size_t)(k1 - k0) * ny * nx;
+    if (total == 0)
+        return;
+    hipLaunchKernelGGL(k_table_rs, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
+}
+
+void launch_table_install(const DevMap &m, const float *raw, const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts,
+                          uint32_t ns, uint32_t *rank, float *table, uint64_t table_size, hipStream_t s)
+{
+    size_t total = (size_t)ns * ny * nx;
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(table_size)), dim3(256), 0, s, rank, (size_t)table_size, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(table_size)), dim3(256), 0, s, reinterpret_cast<uint32_t *>(table), (size_t)table_size,
+                       0x7FC00000u); // quiet NaN = key absent
+    if (total == 0)
+        return;
+    for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_table_install, dim3(grid_for(total)), dim3(256), 0, s, m, raw, xs, nx, ys, ny, ts, ns, rank, table, table_size,
+                           pass);
+}
+
+void launch_table_lookup(const DevMap &m, const float *xyt, size_t n, float *cost, hipStream_t s)
+{
+    if (n)
+        hipLaunchKernelGGL(k_table_lookup, dim3(grid_for(n)), dim3(256), 0, s, m, xyt, n, cost);
+}
+
+void launch_step_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
+                    uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
+                    hipStream_t s)
+{
+    if (n)
+        hipLaunchKernelGGL(k_step_rs, dim3(n), dim3(STEP_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
+                           count, succ, stats);
+}
+
+void launch_shot_path(const DevMap &m, const StepIn &node, const hyas_goal &goal, const double *seg_tab, uint32_t seg_cap, float *out,
+                      uint32_t out_cap, uint32_t *n_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_shot_path, dim3(1), dim3(256), 0, s, m, node, goal, seg_tab, seg_cap, out, out_cap, n_out);
+}
+
+} // namespace hyas

@@ -1,0 +1,363 @@
+// hyas_rs.h -- Reeds-Shepp solver laid out for wide execution.
+//
+// The reference (src/ReedsShepp.cpp:73-503) walks 44 closed-form candidates in
+// a fixed order through five family functions (CSC, CCC, CCCC, CCSC, CCSCC)
+// and keeps a candidate when it is strictly shorter than the running best.
+// Here every candidate is a row of one table -- (base formula, symmetry,
+// backwards?, word) -- so 44 lanes can evaluate one candidate each and a
+// per-family arg-min (lowest index on ties) reproduces the sequential scan
+// exactly; a single thread can also walk the table in order.
+#pragma once
+#include "../../include/hyas_math.h"
+
+#define RS_HD __host__ __device__ __forceinline__
+
+namespace hyas
+{
+namespace rs
+{
+
+#define RS_PI HY_PI
+// 10 * DBL_EPSILON, src/ReedsShepp.cpp:48
+#define RS_ZERO 2.220446049250313e-15
+
+struct Path
+{
+    int type;      // row of the segment-type table below
+    double len[5]; // signed segment lengths, in units of the turning radius
+    double total;  // sum of |len|
+};
+
+// Segment kinds per word, src/ReedsShepp.cpp:505-525 (1 left, 2 straight, 3 right, 0 none)
+RS_HD int seg_kind(int type, int i)
+{
+    // packed 3 bits per segment
+    const unsigned w[18] = {
+        1 | 3 << 3 | 1 << 6,           3 | 1 << 3 | 3 << 6,           1 | 3 << 3 | 1 << 6 | 3 << 9,  3 | 1 << 3 | 3 << 6 | 1 << 9,
+        1 | 3 << 3 | 2 << 6 | 1 << 9,  3 | 1 << 3 | 2 << 6 | 3 << 9,  1 | 2 << 3 | 3 << 6 | 1 << 9,  3 | 2 << 3 | 1 << 6 | 3 << 9,
+        1 | 3 << 3 | 2 << 6 | 3 << 9,  3 | 1 << 3 | 2 << 6 | 1 << 9,  3 | 2 << 3 | 3 << 6 | 1 << 9,  1 | 2 << 3 | 1 << 6 | 3 << 9,
+        1 | 2 << 3 | 3 << 6,           3 | 2 << 3 | 1 << 6,           1 | 2 << 3 | 1 << 6,           3 | 2 << 3 | 3 << 6,
+        1 | 3 << 3 | 2 << 6 | 1 << 9 | 3 << 12, 3 | 1 << 3 | 2 << 6 | 3 << 9 | 1 << 12};
+    return (w[type] >> (3 * i)) & 7;
+}
+
+RS_HD double mod2pi(double x) // :50-58
+{
+    double v = hy_fmod(x, 2. * RS_PI);
+    if (v < -RS_PI)
+        v += 2. * RS_PI;
+    else if (v > RS_PI)
+        v -= 2. * RS_PI;
+    return v;
+}
+RS_HD void polar(double x, double y, double &r, double &theta) // :59-63
+{
+    r = hy_sqrt(x * x + y * y);
+    theta = hy_atan2(y, x);
+}
+RS_HD void tau_omega(double u, double v, double xi, double eta, double phi, double &tau, double &omega) // :64-70
+{
+    double delta = mod2pi(u - v), A = hy_sin(u) - hy_sin(delta), B = hy_cos(u) - hy_cos(delta) - 1.;
+    double t1 = hy_atan2(eta * A - xi * B, xi * A + eta * B), t2 = 2. * (hy_cos(delta) - hy_cos(v) - hy_cos(u)) + 3;
+    tau = (t2 < 0) ? mod2pi(t1 + RS_PI) : mod2pi(t1);
+    omega = mod2pi(tau - u + v - phi);
+}
+
+// The eight base formulas, :73-108, :160-175, :229-260, :312-345, :449-467.
+RS_HD bool base_formula(int f, double x, double y, double phi, double &t, double &u, double &v)
+{
+    const double sp = hy_sin(phi), cp = hy_cos(phi);
+    switch (f)
+    {
+    case 0: // LpSpLp (8.1)
+    {
+        polar(x - sp, y - 1. + cp, u, t);
+        if (t >= -RS_ZERO)
+        {
+            v = mod2pi(phi - t);
+            if (v >= -RS_ZERO)
+                return true;
+        }
+        return false;
+    }
+    case 1: // LpSpRp (8.2)
+    {
+        double t1, u1;
+        polar(x + sp, y - 1. - cp, u1, t1);
+        u1 = u1 * u1;
+        if (u1 >= 4.)
+        {
+            u = hy_sqrt(u1 - 4.);
+            double theta = hy_atan2(2., u);
+            t = mod2pi(t1 + theta);
+            v = mod2pi(t - phi);
+            return t >= -RS_ZERO && v >= -RS_ZERO;
+        }
+        return false;
+    }
+    case 2: // LpRmL (8.3/8.4)
+    {
+        double xi = x - sp, eta = y - 1. + cp, u1, theta;
+        polar(xi, eta, u1, theta);
+        if (u1 <= 4.)
+        {
+            u = -2. * hy_asin(.25 * u1);
+            t = mod2pi(theta + .5 * u + RS_PI);
+            v = mod2pi(phi - t + u);
+            return t >= -RS_ZERO && u <= RS_ZERO;
+        }
+        return false;
+    }
+    case 3: // LpRupLumRm (8.7)
+    {
+        double xi = x + sp, eta = y - 1. - cp, rho = .25 * (2. + hy_sqrt(xi * xi + eta * eta));
+        if (rho <= 1.)
+        {
+            u = hy_acos(rho);
+            tau_omega(u, -u, xi, eta, phi, t, v);
+            return t >= -RS_ZERO && v <= RS_ZERO;
+        }
+        return false;
+    }
+    case 4: // LpRumLumRp (8.8)
+    {
+        double xi = x + sp, eta = y - 1. - cp, rho = (20. - xi * xi - eta * eta) / 16.;
+        if (rho >= 0 && rho <= 1)
+        {
+            u = -hy_acos(rho);
+            if (u >= -.5 * RS_PI)
+            {
+                tau_omega(u, u, xi, eta, phi, t, v);
+                return t >= -RS_ZERO && v >= -RS_ZERO;
+            }
+        }
+        return false;
+    }
+    case 5: // LpRmSmLm (8.9)
+    {
+        double xi = x - sp, eta = y - 1. + cp, rho, theta;
+        polar(xi, eta, rho, theta);
+        if (rho >= 2.)
+        {
+            double r = hy_sqrt(rho * rho - 4.);
+            u = 2. - r;
+            t = mod2pi(theta + hy_atan2(r, -2.));
+            v = mod2pi(phi - .5 * RS_PI - t);
+            return t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO;
+        }
+        return false;
+    }
+    case 6: // LpRmSmRm (8.10)
+    {
+        double xi = x + sp, eta = y - 1. - cp, rho, theta;
+        polar(-eta, xi, rho, theta);
+        if (rho >= 2.)
+        {
+            t = theta;
+            u = 2. - rho;
+            v = mod2pi(t + .5 * RS_PI - phi);
+            return t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO;
+        }
+        return false;
+    }
+    default: // LpRmSLmRp (8.11)
+    {
+        double xi = x + sp, eta = y - 1. - cp, rho, theta;
+        polar(xi, eta, rho, theta);
+        if (rho >= 2.)
+        {
+            u = 4. - hy_sqrt(rho * rho - 4.);
+            if (u <= RS_ZERO)
+            {
+                t = mod2pi(hy_atan2((4 - u) * xi - 2 * eta, -2 * xi + (u - 4) * eta));
+                v = mod2pi(t - phi);
+                return t >= -RS_ZERO && v >= -RS_ZERO;
+            }
+        }
+        return false;
+    }
+    }
+}
+
+// Candidate list in reference order.  Groups of four share a base formula and
+// run through the symmetries (x,y,phi), (-x,y,-phi) "timeflip", (x,-y,-phi)
+// "reflect", (-x,-y,phi) both.  group: base formula, uses backwards frame?,
+// family (0 CSC, 1 CCC, 2 CCCC, 3 CCSC, 4 CCSCC), word of the un-reflected
+// pair (the reflected pair uses word+1), length layout.
+#define RS_NUM_CANDIDATES 44
+#define RS_NUM_FAMILIES 5
+RS_HD void group_info(int g, int &formula, int &backwards, int &family, int &word, int &layout)
+{
+    //                    g:  0   1   2   3   4   5   6   7   8   9  10
+    const signed char F[11] = {0, 1, 2, 2, 3, 4, 5, 6, 5, 6, 7};
+    const signed char B[11] = {0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0};
+    const signed char M[11] = {0, 0, 1, 1, 2, 2, 3, 3, 3, 3, 4};
+    const signed char W[11] = {14, 12, 0, 0, 2, 2, 4, 8, 6, 10, 16};
+    // layout: 0 (t,u,v) 1 (v,u,t) 2 (t,u,-u,v) 3 (t,u,u,v) 4 (t,-pi/2,u,v) 5 (v,u,-pi/2,t) 6 (t,-pi/2,u,-pi/2,v)
+    const signed char Lay[11] = {0, 0, 0, 1, 2, 3, 4, 4, 5, 5, 6};
+    formula = F[g], backwards = B[g], family = M[g], word = W[g], layout = Lay[g];
+}
+RS_HD int family_first(int fam)
+{
+    const int first[6] = {0, 8, 16, 24, 40, 44};
+    return first[fam];
+}
+
+// Evaluates candidate c for the normalised goal (x, y, phi).  On success fills
+// p (word, signed lengths, total) and L, the length the family compares
+// (|t|+|u|+|v|, with 2|u| in the CCCC family).
+RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
+{
+    int formula, backwards, family, word, layout;
+    group_info(c >> 2, formula, backwards, family, word, layout);
+    const int sym = c & 3;
+    double X = x, Y = y;
+    if (backwards) // :205, :400
+    {
+        double cp = hy_cos(phi), sp = hy_sin(phi);
+        X = x * cp + y * sp;
+        Y = x * sp - y * cp;
+    }
+    const bool flip = (sym & 1) != 0, reflect = (sym & 2) != 0;
+    const double ax = flip ? -X : X;
+    const double ay = reflect ? -Y : Y;
+    const double aphi = (flip != reflect) ? -phi : phi;
+    double t, u, v;
+    if (!base_formula(formula, ax, ay, aphi, t, u, v))
+        return false;
+    L = (family == 2) ? hy_fabs(t) + 2. * hy_fabs(u) + hy_fabs(v) : hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+    const double hp = flip ? .5 * RS_PI : -.5 * RS_PI; // the fixed quarter turn of CCSC/CCSCC
+    if (flip)
+        t = -t, u = -u, v = -v;
+    p.type = word + (reflect ? 1 : 0);
+    double a = 0, b = 0, cc = 0, d = 0, e = 0;
+    switch (layout)
+    {
+    case 0:
+        a = t, b = u, cc = v;
+        break;
+    case 1:
+        a = v, b = u, cc = t;
+        break;
+    case 2:
+        a = t, b = u, cc = -u, d = v;
+        break;
+    case 3:
+        a = t, b = u, cc = u, d = v;
+        break;
+    case 4:
+        a = t, b = hp, cc = u, d = v;
+        break;
+    case 5:
+        a = v, b = u, cc = hp, d = t;
+        break;
+    default:
+        a = t, b = hp, cc = u, d = hp, e = v;
+        break;
+    }
+    p.len[0] = a, p.len[1] = b, p.len[2] = cc, p.len[3] = d, p.len[4] = e;
+    p.total = hy_fabs(a) + hy_fabs(b) + hy_fabs(cc) + hy_fabs(d) + hy_fabs(e); // :527-537
+    return true;
+}
+
+// Starting bound of each family's scan: path.length() minus the fixed quarter
+// turns its comparison leaves out (:348, :470).
+RS_HD double family_bound(int fam, double best_total)
+{
+    if (fam == 3)
+        return best_total - .5 * RS_PI;
+    if (fam == 4)
+        return best_total - RS_PI;
+    return best_total;
+}
+
+RS_HD Path empty_path() // include/ReedsShepp.h:65-67
+{
+    Path p;
+    p.type = 0;
+    p.len[0] = 1.7976931348623157e308;
+    p.len[1] = p.len[2] = p.len[3] = p.len[4] = 0;
+    p.total = 1.7976931348623157e308;
+    return p;
+}
+
+// One thread walks all candidates in order (:494-503).
+RS_HD Path solve_serial(double x, double y, double phi)
+{
+    Path best = empty_path();
+    for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
+    {
+        double lmin = family_bound(fam, best.total);
+        for (int c = family_first(fam); c < family_first(fam + 1); ++c)
+        {
+            Path p;
+            double L;
+            if (candidate(c, x, y, phi, p, L) && lmin > L)
+            {
+                best = p;
+                lmin = L;
+            }
+        }
+    }
+    return best;
+}
+
+// Goal in the frame of q0, scaled by the turning radius (:544-550).
+RS_HD void normalise(const double q0[3], const double q1[3], double rho, double &x, double &y, double &phi)
+{
+    double dx = q1[0] - q0[0], dy = q1[1] - q0[1];
+    phi = q1[2] - q0[2];
+    double c = hy_cos(q0[2]), s = hy_sin(q0[2]);
+    x = (c * dx + s * dy) / rho;
+    y = (-s * dx + c * dy) / rho;
+}
+
+// State at arc length seg (units of rho) along the path from q0 (:576-625).
+RS_HD void interpolate(const double q0[3], const Path &path, double seg, double rho, double s[3])
+{
+    if (seg < 0.0)
+        seg = 0.0;
+    if (seg > path.total)
+        seg = path.total;
+    double phi, v;
+    s[0] = s[1] = 0.0;
+    s[2] = q0[2];
+    for (int i = 0; i < 5 && seg > 0; ++i)
+    {
+        const double li = path.len[i];
+        if (li < 0)
+        {
+            v = (-seg < li) ? li : -seg; // std::max(-seg, li)
+            seg += v;
+        }
+        else
+        {
+            v = (li < seg) ? li : seg; // std::min(seg, li)
+            seg -= v;
+        }
+        phi = s[2];
+        const int kind = seg_kind(path.type, i);
+        if (kind == 1)
+        {
+            s[0] += (hy_sin(phi + v) - hy_sin(phi));
+            s[1] += (-hy_cos(phi + v) + hy_cos(phi));
+            s[2] = phi + v;
+        }
+        else if (kind == 3)
+        {
+            s[0] += (-hy_sin(phi - v) + hy_sin(phi));
+            s[1] += (hy_cos(phi - v) - hy_cos(phi));
+            s[2] = phi - v;
+        }
+        else if (kind == 2)
+        {
+            s[0] += (v * hy_cos(phi));
+            s[1] += (v * hy_sin(phi));
+        }
+    }
+    s[0] = s[0] * rho + q0[0];
+    s[1] = s[1] * rho + q0[1];
+}
+
+} // namespace rs
+} // namespace hyas

@@ -1,0 +1,680 @@
+// hyas_search.hip -- batched Hybrid A* driver: the open/closed-set bookkeeping
+// of HybridAStar::GetPath (src/hybrid_a_star.cpp:41-311) stays on the host,
+// one state machine per query; every round each live query pops one node and
+// all popped nodes go through ONE expansion-step kernel launch (successors +
+// verdict + g + h + analytic shot).  Queries are independent, so the serial
+// pop order of every single query is untouched and its expansion sequence is
+// the one a one-query-at-a-time run produces.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+#include "hyas_ctx.h"
+
+namespace hyas
+{
+namespace
+{
+
+struct SNode
+{
+    float x, y, t, g, h;
+    int32_t prim;
+    int32_t pred;     // arena index, -1 = none (shared_ptr chain in the reference)
+    int32_t dup_next; // chain of the duplicate-check hash, -1 = end
+    int32_t dup_prev; // >= 0 arena index, < 0: -(bucket + 2), head of its bucket
+};
+
+struct HeapItem
+{
+    float f;
+    uint32_t seq;
+    int32_t node;
+};
+// Open list order: lowest f = g + h first (CompareNodes,
+// include/hybrid_a_star.h:31-43); equal f: earliest push first.  (Boost's
+// binomial heap leaves the order of equal keys unspecified.)
+struct HeapLess
+{
+    bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f > b.f || (a.f == b.f && a.seq > b.seq); }
+};
+
+// idx -> {g, open, closed}: the three Node3D fields GetPath reads back from
+// nodes3D[] (:101, :110, :264, :271).  Open addressing, grows at 50 % load.
+struct CellMap
+{
+    struct Slot
+    {
+        int32_t key;
+        float g;
+        uint8_t open, closed;
+    };
+    std::vector<Slot> slots;
+    size_t used = 0;
+    void init(size_t cap)
+    {
+        slots.assign(cap, Slot{-1, 999.f, 0, 0});
+        used = 0;
+    }
+    static size_t hash(int32_t k) { return (size_t)((uint32_t)k * 2654435761u); }
+    Slot *find(int32_t key)
+    {
+        size_t mask = slots.size() - 1, i = hash(key) & mask;
+        while (slots[i].key != -1)
+        {
+            if (slots[i].key == key)
+                return &slots[i];
+            i = (i + 1) & mask;
+        }
+        return nullptr;
+    }
+    Slot &get(int32_t key)
+    {
+        if ((used + 1) * 2 > slots.size())
+            grow();
+        size_t mask = slots.size() - 1, i = hash(key) & mask;
+        while (slots[i].key != -1 && slots[i].key != key)
+            i = (i + 1) & mask;
+        if (slots[i].key == -1)
+        {
+            slots[i] = Slot{key, 999.f, 0, 0}; // Node3D() default g, include/node3d.h:17
+            ++used;
+        }
+        return slots[i];
+    }
+    void grow()
+    {
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(old.size() * 2, Slot{-1, 999.f, 0, 0});
+        used = 0;
+        for (const Slot &s : old)
+            if (s.key != -1)
+                get(s.key) = s;
+    }
+};
+
+struct Query
+{
+    hyas_goal goal;
+    SNode start;
+    std::vector<SNode> arena;
+    std::vector<HeapItem> heap;
+    uint32_t seq = 0;
+    CellMap cells;
+    std::vector<int32_t> dup_head; // spatial hash over the open list
+    int iterations = 0, counter = 0, N = 0;
+    int cur = -1, cur_idx = 0; // node being expanded this round
+    bool shoot = false;
+    bool done = false;
+    int shot_from = -1; // >= 0: finished through an analytic shot from this node
+    hyas_result res{};
+    std::vector<int32_t> expanded;
+    std::vector<float> path;
+};
+
+struct Driver
+{
+    hyas_ctx *c;
+    const DevMap &m;
+    const hyas_params &P;
+    float rad3; // ConvertDegToRad(3), src/hybrid_a_star.cpp:973
+    Driver(hyas_ctx *ctx) : c(ctx), m(ctx->dm), P(ctx->P), rad3(deg2rad(3)) {}
+
+    // ---- duplicate check -------------------------------------------------
+    // DuplicateCheck (:968-980) asks whether ANY open-list entry lies within
+    // 0.05 m / 0.05 m / 3 deg of the candidate.  The open list is mirrored in
+    // a hash of 0.1 m buckets; every entry of the 3x3 neighbourhood is put
+    // through the reference's own comparison, so the answer is the linear
+    // scan's answer.
+    static int32_t bucket_coord(float v) { return (int32_t)std::floor((double)v * 10.0); }
+    static size_t bucket_hash(int32_t bx, int32_t by, size_t mask)
+    {
+        return (size_t)(((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349663u)) & mask;
+    }
+    void dup_link(Query &q, int32_t id)
+    {
+        SNode &n = q.arena[id];
+        size_t b = bucket_hash(bucket_coord(n.x), bucket_coord(n.y), q.dup_head.size() - 1);
+        n.dup_next = q.dup_head[b];
+        n.dup_prev = -(int32_t)b - 2;
+        if (n.dup_next >= 0)
+            q.arena[n.dup_next].dup_prev = id;
+        q.dup_head[b] = id;
+    }
+    void dup_insert(Query &q, int32_t id)
+    {
+        if (q.heap.size() > q.dup_head.size())
+        {
+            // rebuild with four times the buckets; the heap holds the live set
+            q.dup_head.assign(q.dup_head.size() * 4, -1);
+            for (const HeapItem &e : q.heap)
+                if (e.node != id)
+                    dup_link(q, e.node);
+        }
+        dup_link(q, id);
+    }
+    void dup_remove(Query &q, int32_t id)
+    {
+        SNode &n = q.arena[id];
+        if (n.dup_prev >= 0)
+            q.arena[n.dup_prev].dup_next = n.dup_next;
+        else
+            q.dup_head[(size_t)(-(n.dup_prev + 2))] = n.dup_next;
+        if (n.dup_next >= 0)
+            q.arena[n.dup_next].dup_prev = n.dup_prev;
+        n.dup_next = -1, n.dup_prev = -1;
+    }
+    bool dup_exists(const Query &q, float x, float y, float t) const
+    {
+        const int32_t bx = bucket_coord(x), by = bucket_coord(y);
+        const size_t mask = q.dup_head.size() - 1;
+        size_t seen[9];
+        int nseen = 0;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+            {
+                size_t b = bucket_hash(bx + dx, by + dy, mask);
+                bool again = false;
+                for (int k = 0; k < nseen; ++k)
+                    again |= (seen[k] == b);
+                if (again)
+                    continue;
+                seen[nseen++] = b;
+                for (int32_t id = q.dup_head[b]; id >= 0; id = q.arena[id].dup_next)
+                {
+                    const SNode &e = q.arena[id];
+                    if ((double)hy_fabsf(e.x - x) < 0.05 && (double)hy_fabsf(e.y - y) < 0.05 && hy_fabsf(e.t - t) < rad3)
+                        return true;
+                }
+            }
+        return false;
+    }
+
+    // ---- heap ------------------------------------------------------------
+    void push(Query &q, const SNode &n)
+    {
+        q.arena.push_back(n);
+        int32_t id = (int32_t)q.arena.size() - 1;
+        q.heap.push_back(HeapItem{n.g + n.h, q.seq++, id}); // getTotalCost(), include/node3d.h:36
+        std::push_heap(q.heap.begin(), q.heap.end(), HeapLess());
+        dup_insert(q, id);
+    }
+    void pop(Query &q)
+    {
+        dup_remove(q, q.heap.front().node);
+        std::pop_heap(q.heap.begin(), q.heap.end(), HeapLess());
+        q.heap.pop_back();
+    }
+
+    // ---- path assembly -----------------------------------------------------
+    // TracePath (:813-828): back to the first node that "equals" the start
+    // (Node3D::operator==, include/node3d.h:89-98) or to a null predecessor.
+    void trace(const Query &q, int32_t id, std::vector<float> &xyt) const
+    {
+        std::vector<int32_t> chain;
+        while (id >= 0)
+        {
+            chain.push_back(id);
+            const SNode &n = q.arena[id];
+            if (std::abs(n.x - q.start.x) < 1e-2 && std::abs(n.y - q.start.y) < 1e-2 && std::abs(n.t - q.start.t) < 1e-2)
+                break;
+            id = n.pred;
+        }
+        xyt.clear();
+        for (size_t i = chain.size(); i-- > 0;)
+        {
+            const SNode &n = q.arena[chain[i]];
+            xyt.push_back(n.x), xyt.push_back(n.y), xyt.push_back(n.t);
+        }
+    }
+    // Utility::RemoveDuplicates (src/utility.cpp:2091-2109): of two poses closer
+    // than 1e-3 the EARLIER one is erased.
+    static void remove_duplicates(std::vector<float> &p)
+    {
+        if (p.empty())
+            return;
+        for (uint32_t i = 0; i < p.size() / 3 - 1; i++)
+        {
+            float d = normf(sub(f2(p[3 * i], p[3 * i + 1]), f2(p[3 * i + 3], p[3 * i + 4])));
+            if ((double)d < 1e-3)
+            {
+                p.erase(p.begin() + 3 * i, p.begin() + 3 * i + 3);
+                i = i - 1;
+            }
+        }
+    }
+    void finish(Query &q, int status, int32_t id)
+    {
+        q.res.status = status;
+        q.res.g_final = q.arena[id].g;
+        remove_duplicates(q.path); // GetPath, then calculatePath :994 again
+        remove_duplicates(q.path);
+        q.res.path_len = (int32_t)(q.path.size() / 3);
+        double len = 0;
+        for (size_t i = 1; i < q.path.size() / 3; ++i)
+            len += (double)normf(sub(f2(q.path[3 * i], q.path[3 * i + 1]), f2(q.path[3 * i - 3], q.path[3 * i - 2])));
+        q.res.path_length = (float)len;
+        q.done = true;
+    }
+
+    // ---- one query, host side of one round --------------------------------
+    // Pops until a node has to be expanded (:80-147).  Returns true when the
+    // query wants a slot in this round's kernel launch.
+    bool advance(Query &q)
+    {
+        while (!q.heap.empty())
+        {
+            const int32_t pid = q.heap.front().node;
+            q.res.nodes_explored++;
+            const SNode &n = q.arena[pid];
+            const int32_t iPred = idx_3d(m, n.x, n.y, n.t);
+            q.iterations++;
+            CellMap::Slot &cell = q.cells.get(iPred);
+            if (cell.closed)
+            {
+                pop(q);
+                continue;
+            }
+            cell.closed = 1, cell.open = 0;
+            pop(q);
+            if (q.iterations > P.max_iterations)
+            {
+                trace(q, pid, q.path);
+                finish(q, HYAS_STATUS_MAX_ITER, pid);
+                return false;
+            }
+            // Utility::IsCloseEnough, src/utility.cpp:1132-1163
+            {
+                const float dist = normf(sub(f2(n.x, n.y), f2(q.goal.x, q.goal.y)));
+                const float dist_range = P.goal_range * m.res_f;
+                const float ang_range = (float)(2 * HY_PI / P.headings);
+                if (dist < dist_range && hy_fabsf(rad_norm(n.t - q.goal.t)) <= ang_range)
+                {
+                    trace(q, pid, q.path);
+                    finish(q, HYAS_STATUS_GOAL, pid);
+                    return false;
+                }
+            }
+            q.res.nodes_expanded++;
+            q.expanded.push_back(iPred);
+            q.shoot = false;
+            if (P.analytical_expansion)
+            {
+                if (P.analytical_expansion_every_point)
+                    q.shoot = true;
+                else if (q.counter == q.N)
+                {
+                    q.N = (int)n.h;
+                    q.counter = 0;
+                    q.shoot = true;
+                }
+                else
+                    q.counter++;
+            }
+            q.cur = pid, q.cur_idx = iPred;
+            return true;
+        }
+        q.res.status = HYAS_STATUS_NO_PATH;
+        q.done = true;
+        return false;
+    }
+
+    // Takes the kernel's answer for the node popped by advance() (:243-305).
+    void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ)
+    {
+        const int32_t pid = q.cur;
+        if (q.shoot && shot_ok)
+        {
+            q.shot_from = pid;
+            q.res.shot_length = shot_len;
+            q.done = true; // path assembled once the curve samples are fetched
+            return;
+        }
+        const SNode pred = q.arena[pid];
+        q.res.successors += count >> 4; // motion-set entries that received a verdict
+        count &= 15;
+        for (int k = 0; k < count; ++k)
+        {
+            const hyas_succ &s = succ[k];
+            if (dup_exists(q, s.x, s.y, s.t))
+                continue;
+            const int32_t iSucc = s.idx;
+            CellMap::Slot &cell = q.cells.get(iSucc);
+            if (cell.closed)
+                continue;
+            const float newG = s.g;
+            if (!cell.open || newG < cell.g)
+            {
+                SNode n{s.x, s.y, s.t, s.g, s.h, (int32_t)s.prim, pid, -1, -1};
+                if (q.cur_idx == iSucc)
+                {
+                    if (n.g + n.h > pred.g + pred.h + P.tie_breaker)
+                        continue;
+                    n.pred = pred.pred;
+                }
+                cell.g = n.g, cell.open = 1, cell.closed = 0;
+                push(q, n);
+            }
+        }
+    }
+};
+
+// Minimal fork-join pool: the calling thread takes part, workers spin between
+// rounds (a round lasts tens of microseconds).
+class Pool
+{
+  public:
+    explicit Pool(int nthreads) : n_(std::max(1, nthreads))
+    {
+        for (int i = 1; i < n_; ++i)
+            th_.emplace_back([this] { worker(); });
+    }
+    ~Pool()
+    {
+        stop_.store(true, std::memory_order_release);
+        gen_.fetch_add(1, std::memory_order_acq_rel);
+        for (auto &t : th_)
+            t.join();
+    }
+    void run(size_t count, const std::function<void(size_t, size_t)> &fn)
+    {
+        if (count == 0)
+            return;
+        if (n_ == 1 || count < 64)
+        {
+            fn(0, count);
+            return;
+        }
+        fn_ = &fn;
+        count_ = count;
+        chunk_ = std::max<size_t>(16, count / (size_t)(n_ * 4));
+        next_.store(0, std::memory_order_relaxed);
+        pending_.store(n_ - 1, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_acq_rel);
+        work();
+        while (pending_.load(std::memory_order_acquire) != 0)
+            cpu_relax();
+    }
+
+  private:
+    static void cpu_relax() { __builtin_ia32_pause(); }
+    void work()
+    {
+        for (;;)
+        {
+            size_t b = next_.fetch_add(chunk_, std::memory_order_relaxed);
+            if (b >= count_)
+                break;
+            (*fn_)(b, std::min(count_, b + chunk_));
+        }
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        for (;;)
+        {
+            int spins = 0;
+            while (gen_.load(std::memory_order_acquire) == seen)
+            {
+                if (++spins > 20000)
+                    std::this_thread::yield();
+                else
+                    cpu_relax();
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            if (stop_.load(std::memory_order_acquire))
+                return;
+            work();
+            pending_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<bool> stop_{false};
+    std::atomic<size_t> next_{0};
+    std::atomic<int> pending_{0};
+    const std::function<void(size_t, size_t)> *fn_ = nullptr;
+    size_t count_ = 0, chunk_ = 1;
+};
+
+int host_threads()
+{
+    if (const char *e = std::getenv("HYAS_THREADS"))
+    {
+        int v = std::atoi(e);
+        if (v >= 1)
+            return std::min(v, 256);
+    }
+    unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(std::max<unsigned>(hc, 1), 16);
+}
+
+} // namespace
+
+int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out)
+{
+    HYAS_HIP(c, hipSetDevice(c->device));
+    Driver D(c);
+    const DevMap &m = c->dm;
+    const int K = m.n_succ;
+    reset_timers(c);
+    c->paths.assign(n, std::vector<float>());
+    c->expanded.assign(n, std::vector<int32_t>());
+    if (n == 0)
+        return HYAS_OK;
+    Pool pool(host_threads());
+
+    // Queries are processed in chunks so the per-query 2D cost maps of one
+    // chunk fit a fixed device buffer.
+    size_t chunk_cap = 4096;
+    if (const char *e = std::getenv("HYAS_CHUNK"))
+        chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
+    const size_t twod = c->twod_size;
+    std::vector<float> shot_buf;
+
+    for (size_t base = 0; base < n; base += chunk_cap)
+    {
+        const size_t cn = std::min(chunk_cap, n - base);
+        std::vector<Query> Q(cn);
+
+        // staging layout (one pinned block, one device block)
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_in = take(cn * sizeof(StepIn));
+        const size_t o_succ = take(cn * K * sizeof(hyas_succ)), o_len = take(cn * sizeof(float)), o_ok = take(cn), o_cnt = take(cn);
+        const size_t o_goal = take(cn * sizeof(hyas_goal));
+        const size_t o_twod_host = take(cn * twod * sizeof(float));
+        int rc = ensure_scratch(c, o_twod_host, off);
+        if (rc != HYAS_OK)
+            return rc;
+        if ((rc = ensure_twod(c, cn * twod * sizeof(float))) != HYAS_OK)
+            return rc;
+        char *hs = (char *)c->h_scratch, *ds = (char *)c->d_scratch;
+        StepIn *h_in = (StepIn *)(hs + o_in);
+        hyas_goal *h_goal = (hyas_goal *)(hs + o_goal);
+        float *h_twod = (float *)(hs + o_twod_host);
+        const hyas_succ *h_succ = (const hyas_succ *)(hs + o_succ);
+        const float *h_len = (const float *)(hs + o_len);
+        const uint8_t *h_ok = (const uint8_t *)(hs + o_ok), *h_cnt = (const uint8_t *)(hs + o_cnt);
+
+        // makePlan pre-checks (src/hybrid_a_star_planner.cpp:126-155): start
+        // and goal poses through the pose test on the GPU
+        std::vector<float> poses(cn * 6);
+        for (size_t i = 0; i < cn; ++i)
+        {
+            const float *s = starts + 3 * (base + i), *g = goals + 3 * (base + i);
+            // Utility::TypeConversion(PoseStamped -> Node3D), src/utility.cpp:7-13
+            poses[6 * i] = s[0], poses[6 * i + 1] = s[1], poses[6 * i + 2] = rad_0_2pi(s[2]);
+            poses[6 * i + 3] = g[0], poses[6 * i + 4] = g[1], poses[6 * i + 5] = rad_0_2pi(g[2]);
+        }
+        std::vector<uint8_t> pose_ok(cn * 2);
+        rc = hyas_collision_batch(c, HYAS_MODE_POLYGON, poses.data(), nullptr, cn * 2, pose_ok.data());
+        if (rc != HYAS_OK)
+            return rc;
+
+        // per-query set-up: 2D cost map, start node
+        pool.run(cn, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i)
+            {
+                Query &q = Q[i];
+                const float *p = &poses[6 * i];
+                q.goal = hyas_goal{p[3], p[4], p[5]};
+                h_goal[i] = q.goal;
+                q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1}; // Node3D(): g = 999, prim = 0
+                uint32_t gx, gy;
+                bool bad = !pose_ok[2 * i];
+                if (!world_to_map(m, p[3], p[4], gx, gy))
+                    bad = true;
+                else if (pose_ok[2 * i + 1] && c->charmap[gx + gy * m.w] > 252)
+                    bad = true;
+                if (bad)
+                {
+                    q.res.status = HYAS_STATUS_BAD_POSE;
+                    q.done = true;
+                    std::fill(h_twod + i * twod, h_twod + (i + 1) * twod, -1.f);
+                    continue;
+                }
+                flood_2d(c, q.goal.x, q.goal.y, h_twod + i * twod);
+                q.cells.init(1024);
+                q.dup_head.assign(1 << 14, -1);
+                q.arena.reserve(1024);
+            }
+        });
+        // the start node's heuristic (:63) comes from the same table / 2D map the
+        // kernels use: evaluate it on the host copy of the 2D map + a table lookup
+        {
+            std::vector<float> rel(cn * 3), cost(cn);
+            for (size_t i = 0; i < cn; ++i)
+            {
+                const Query &q = Q[i];
+                rel[3 * i] = hy_fabsf(q.goal.x - q.start.x), rel[3 * i + 1] = hy_fabsf(q.goal.y - q.start.y);
+                rel[3 * i + 2] = q.goal.t - q.start.t;
+            }
+            rc = hyas_table_lookup(c, rel.data(), cn, cost.data());
+            if (rc != HYAS_OK)
+                return rc;
+            for (size_t i = 0; i < cn; ++i)
+            {
+                Query &q = Q[i];
+                if (q.done)
+                    continue;
+                float two_d = 0;
+                int id = idx_2d(m, q.start.x, q.start.y);
+                if (id >= 0 && (size_t)id < twod && h_twod[i * twod + id] >= 0)
+                    two_d = h_twod[i * twod + id];
+                q.start.h = fmaxf_(cost[i], two_d);
+                q.N = (int)q.start.h;
+                D.push(q, q.start);
+                CellMap::Slot &cell = q.cells.get(idx_3d(m, q.start.x, q.start.y, q.start.t));
+                cell.g = q.start.g, cell.open = 1, cell.closed = 0;
+            }
+        }
+
+        // the calls above reuse the device scratch: size it for the rounds now
+        if ((rc = ensure_scratch(c, o_twod_host, off)) != HYAS_OK)
+            return rc;
+        ds = (char *)c->d_scratch;
+        HYAS_HIP(c, hipMemcpyAsync(c->d_twod, h_twod, cn * twod * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HYAS_HIP(c, hipMemcpyAsync(ds + o_goal, h_goal, cn * sizeof(hyas_goal), hipMemcpyHostToDevice, c->stream));
+        HYAS_HIP(c, hipStreamSynchronize(c->stream));
+
+
+        // rounds
+        std::vector<uint32_t> live(cn), slot_of;
+        for (size_t i = 0; i < cn; ++i)
+            live[i] = (uint32_t)i;
+        std::vector<uint8_t> wants(cn);
+        while (true)
+        {
+            // host: pop phase
+            pool.run(live.size(), [&](size_t a, size_t b) {
+                for (size_t k = a; k < b; ++k)
+                {
+                    Query &q = Q[live[k]];
+                    wants[live[k]] = (!q.done && D.advance(q)) ? 1 : 0;
+                }
+            });
+            slot_of.clear();
+            for (uint32_t qi : live)
+                if (wants[qi])
+                    slot_of.push_back(qi);
+            live = slot_of; // queries that finished drop out
+            const size_t ns = live.size();
+            if (ns == 0)
+                break;
+            for (size_t s = 0; s < ns; ++s)
+            {
+                const Query &q = Q[live[s]];
+                const SNode &nd = q.arena[q.cur];
+                h_in[s] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, live[s], q.shoot ? 1u : 0u, 0};
+            }
+            HYAS_HIP(c, hipMemcpyAsync(ds + o_in, h_in, ns * sizeof(StepIn), hipMemcpyHostToDevice, c->stream));
+            timer_begin(c);
+            launch_step_rs(m, (const StepIn *)(ds + o_in), (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap,
+                           (uint8_t *)(ds + o_ok), (float *)(ds + o_len), (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), nullptr,
+                           c->stream);
+            (void)hipEventRecord(c->ev1, c->stream);
+            HYAS_HIP(c, hipMemcpyAsync(hs + o_succ, ds + o_succ, ns * K * sizeof(hyas_succ), hipMemcpyDeviceToHost, c->stream));
+            HYAS_HIP(c, hipMemcpyAsync(hs + o_len, ds + o_len, ns * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HYAS_HIP(c, hipMemcpyAsync(hs + o_ok, ds + o_ok, ns, hipMemcpyDeviceToHost, c->stream));
+            HYAS_HIP(c, hipMemcpyAsync(hs + o_cnt, ds + o_cnt, ns, hipMemcpyDeviceToHost, c->stream));
+            HYAS_HIP(c, hipStreamSynchronize(c->stream));
+            {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
+                    c->k_ms[0] += ms;
+                c->k_launches[0] += 1;
+            }
+            // host: push phase
+            pool.run(ns, [&](size_t a, size_t b) {
+                for (size_t s = a; s < b; ++s)
+                    D.consume(Q[live[s]], h_ok[s], h_len[s], h_cnt[s], h_succ + s * K);
+            });
+        }
+
+        // queries closed by an analytic shot: fetch the curve samples
+        // (:160-172: TracePath + the sampled curve + the goal)
+        for (size_t i = 0; i < cn; ++i)
+        {
+            Query &q = Q[i];
+            if (q.shot_from < 0)
+                continue;
+            const SNode &nd = q.arena[q.shot_from];
+            const uint32_t cap = c->seg_cap;
+            rc = ensure_scratch(c, std::max<size_t>(off, (size_t)cap * 3 * sizeof(float) + 256), 0);
+            if (rc != HYAS_OK)
+                return rc;
+            ds = (char *)c->d_scratch;
+            float *d_pts = (float *)ds;
+            uint32_t *d_n = (uint32_t *)(ds + (size_t)cap * 3 * sizeof(float));
+            StepIn in{nd.x, nd.y, nd.t, nd.g, nd.prim, (uint32_t)i, 1, 0};
+            launch_shot_path(m, in, q.goal, c->d_seg, c->seg_cap, d_pts, cap, d_n, c->stream);
+            uint32_t npts = 0;
+            HYAS_HIP(c, hipMemcpyAsync(&npts, d_n, sizeof npts, hipMemcpyDeviceToHost, c->stream));
+            HYAS_HIP(c, hipStreamSynchronize(c->stream));
+            npts = std::min(npts, cap);
+            shot_buf.resize((size_t)npts * 3);
+            if (npts)
+                HYAS_HIP(c, hipMemcpy(shot_buf.data(), d_pts, (size_t)npts * 3 * sizeof(float), hipMemcpyDeviceToHost));
+            D.trace(q, q.shot_from, q.path);
+            q.path.insert(q.path.end(), shot_buf.begin(), shot_buf.end());
+            q.path.push_back(q.goal.x), q.path.push_back(q.goal.y), q.path.push_back(q.goal.t);
+            D.finish(q, HYAS_STATUS_SHOT, q.shot_from);
+        }
+
+        for (size_t i = 0; i < cn; ++i)
+        {
+            out[base + i] = Q[i].res;
+            c->paths[base + i].swap(Q[i].path);
+            c->expanded[base + i].swap(Q[i].expanded);
+        }
+    }
+    return HYAS_OK;
+}
+
+} // namespace hyas

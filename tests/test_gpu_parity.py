@@ -1,0 +1,223 @@
+"""GPU parity: every C-ABI entry point of libhyas.so against the CPU oracle on
+the same seeded inputs, bit for bit (verdicts, indices, f32/f64 values)."""
+import math
+
+import numpy as np
+import pytest
+
+import orc
+from path_planner_amd import Hyas, Params
+from path_planner_amd import _lib as hl
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(**kw):
+    o = orc.hot_path_params(**kw)
+    h = Params()
+    for name, _ in Params._fields_:
+        setattr(h, name, getattr(o, name))
+    return o, h
+
+
+class Pair:
+    def __init__(self, map_name, res=1.0, ox=0.0, oy=0.0, **kw):
+        po, ph = _params(**kw)
+        self.map = orc.load_map(map_name)
+        self.o = orc.Oracle(po)
+        self.o.set_costmap(self.map, res, ox, oy, build_table=True, nthreads=16)
+        self.h = Hyas(ph)
+        self.h.set_costmap(self.map, res, ox, oy, build_table=True)
+        self.H, self.W = self.map.shape
+        self.res, self.ox, self.oy = res, ox, oy
+
+    def poses(self, n, seed, margin=0.0):
+        rng = np.random.default_rng(seed)
+        x = rng.uniform(self.ox - margin, self.ox + self.W * self.res + margin, n)
+        y = rng.uniform(self.oy - margin, self.oy + self.H * self.res + margin, n)
+        t = rng.uniform(0, 2 * math.pi, n)
+        return np.stack([x, y, t], 1).astype(np.float32)
+
+    def free_poses(self, n, seed):
+        out = []
+        k = 0
+        while len(out) < n:
+            p = self.poses(4 * n, seed + k)
+            ok = self.o.collision(p)
+            out.extend(p[ok == 1])
+            k += 1
+        return np.array(out[:n], np.float32)
+
+
+@pytest.fixture(scope="module")
+def parking(oracle_built):
+    return Pair("map_parking", position_resolution=2)
+
+
+@pytest.fixture(scope="module")
+def maze(oracle_built):
+    return Pair("map_maze", position_resolution=2, max_iterations=150)
+
+
+def test_obstacles_and_lists(parking):
+    p = parking
+    a, b = p.o.obstacles(), p.h.obstacles()
+    assert a.shape == b.shape and a.shape[0] > 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for key in range(p.W * p.H):
+        assert max(0, p.o.in_range_count(key)) == p.h.in_range_count(key), key
+
+
+def test_footprint_table(parking):
+    a, b = parking.o.footprint_table(), parking.h.footprint_table()
+    assert a.shape == b.shape
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_collision_polygon(parking, maze, with_pred):
+    for p, seed in ((parking, 11), (maze, 12)):
+        xyt = p.poses(40000, seed, margin=1.5)
+        pred = None
+        if with_pred:
+            rng = np.random.default_rng(seed + 100)
+            pred = (xyt[:, :2] + rng.uniform(-0.3, 0.3, (xyt.shape[0], 2))).astype(np.float32)
+        a = p.o.collision(xyt, pred)
+        b = p.h.collision(xyt, pred)
+        assert 0.05 < a.mean() < 0.95
+        assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
+
+
+def test_collision_polygon_edge_cases(parking):
+    p = parking
+    # empty batch, poses on cell borders / map border / just outside
+    assert p.h.collision(np.zeros((0, 3), np.float32)).shape == (0,)
+    xs = np.array([0.0, 1e-7, 0.9999999, 1.0, 59.9995, 59.9999, 60.0, -1e-6, 30.0], np.float32)
+    ys = np.array([0.0, 29.9999, 30.0, 15.0, 15.5, -0.0], np.float32)
+    ts = np.array([0.0, 1e-5, math.pi / 2, math.pi, 6.2831, 3.0], np.float32)
+    g = np.array(np.meshgrid(xs, ys, ts, indexing="ij")).reshape(3, -1).T.astype(np.float32)
+    assert np.array_equal(p.o.collision(g), p.h.collision(g))
+    pred = g[:, :2] + np.float32(0.1)
+    assert np.array_equal(p.o.collision(g, pred), p.h.collision(g, pred))
+
+
+def test_collision_footprint(parking):
+    p = parking
+    xyt = p.poses(50000, 21, margin=1.0)
+    xyt[:, 0] = np.abs(xyt[:, 0])
+    xyt[:, 1] = np.abs(xyt[:, 1])
+    a = p.o.collision(xyt, mode=1)
+    b = p.h.collision(xyt, mode=hl.MODE_FOOTPRINT)
+    assert 0.05 < a.mean() < 0.99
+    assert np.array_equal(a, b)
+    # ragged tail (n not a multiple of 4)
+    for n in (1, 2, 3, 5, 7):
+        assert np.array_equal(p.o.collision(xyt[:n], mode=1), p.h.collision(xyt[:n], mode=1))
+
+
+def test_table(parking):
+    p = parking
+    assert p.o.table_dims() == p.h.table_dims()
+    rng = np.random.default_rng(5)
+    q = np.stack([rng.uniform(0, p.W, 100000), rng.uniform(0, p.H, 100000), rng.uniform(-7, 7, 100000)], 1).astype(np.float32)
+    a, b = p.o.table_lookup(q), p.h.table_lookup(q)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # exact grid points hit every key once
+    nx, ny, ns = p.o.table_dims()
+    gx, gy = np.meshgrid(np.arange(nx) * 0.5, np.arange(ny) * 0.5, indexing="ij")
+    for t in (0.0, 1.0, 3.1, 6.2):
+        g = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, t)], 1).astype(np.float32)
+        assert np.array_equal(p.o.table_lookup(g).view(np.uint32), p.h.table_lookup(g).view(np.uint32))
+
+
+def test_flood(parking, maze):
+    for p, seed in ((parking, 31), (maze, 32)):
+        for g in p.free_poses(4, seed):
+            a, b = p.o.flood(g), p.h.flood(g)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert (a >= 0).sum() >= p.W * p.H - 1
+
+
+def _nodes(p, n, seed):
+    xyt = p.free_poses(n, seed)
+    rng = np.random.default_rng(seed + 1)
+    nodes = np.zeros(n, orc.NODE_DT)
+    nodes["x"], nodes["y"], nodes["t"] = xyt[:, 0], xyt[:, 1], xyt[:, 2]
+    nodes["g"] = (999 + rng.uniform(0, 50, n)).astype(np.float32)
+    nodes["prim"] = rng.integers(0, 6, n)
+    gxyt = p.free_poses(n, seed + 2)
+    goals = np.zeros(n, orc.GOAL_DT)
+    goals["x"], goals["y"], goals["t"] = gxyt[:, 0], gxyt[:, 1], gxyt[:, 2]
+    # a few goals closer than one step to their node (step clipping, src/hybrid_a_star.cpp:607-614)
+    k = n // 10
+    goals["x"][:k] = nodes["x"][:k] + rng.uniform(-0.1, 0.1, k).astype(np.float32)
+    goals["y"][:k] = nodes["y"][:k] + rng.uniform(-0.1, 0.1, k).astype(np.float32)
+    goals["x"][0], goals["y"][0] = nodes["x"][0], nodes["y"][0]  # zero distance: every step skipped
+    return nodes, goals
+
+
+def test_expand(parking, maze):
+    for p, seed in ((parking, 41), (maze, 42)):
+        n = 3000
+        nodes, goals = _nodes(p, n, seed)
+        twod = np.stack([p.o.flood((g["x"], g["y"], g["t"])) for g in goals[:64]])
+        a, ca = p.o.expand(nodes[:64], goals[:64], twod)
+        b, cb = p.h.expand(nodes[:64], goals[:64], twod)
+        assert np.array_equal(ca, cb)
+        assert a.tobytes() == b.tobytes()
+        a, ca = p.o.expand(nodes, goals)
+        b, cb = p.h.expand(nodes, goals)
+        assert np.array_equal(ca, cb)
+        assert ca[0] == 0 and ca.max() == p.o.num_successors()
+        assert a.tobytes() == b.tobytes()
+
+
+def test_shot(parking, maze):
+    for p, seed in ((parking, 51), (maze, 52)):
+        nodes, goals = _nodes(p, 1500, seed)
+        a, la = p.o.shot(nodes, goals)
+        b, lb = p.h.shot(nodes, goals)
+        assert 0.02 < a.mean() < 0.98
+        assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+
+
+def _plan_compare(p, starts, goals):
+    res = p.h.plan_batch(starts, goals)
+    for i in range(len(starts)):
+        r, path, exp = p.o.plan(starts[i], goals[i])
+        assert r.tobytes() == res[i].tobytes(), (i, r, res[i])
+        assert np.array_equal(exp, p.h.expanded(i)), i
+        assert path.tobytes() == p.h.path(i).tobytes(), i
+    return res
+
+
+def test_plan_parking_reference_query(parking):
+    # the reference's fixed start/goal, src/planner.cpp:193-207
+    p = parking
+    res = _plan_compare(p, np.array([[2, p.H - 2, 0]], np.float32), np.array([[p.W - 2, 2, 0]], np.float32))
+    assert res[0]["status"] == hl.STATUS_SHOT
+
+
+def test_plan_batch(parking, maze):
+    for p, seed, n in ((parking, 61, 48), (maze, 62, 48)):
+        s, g = p.free_poses(n, seed), p.free_poses(n, seed + 1)
+        # include rejected poses (occupied start, goal off the map)
+        s[0] = [p.W + 5, 1, 0]
+        g[1] = [-3, 2, 1]
+        res = _plan_compare(p, s, g)
+        assert res[0]["status"] == hl.STATUS_BAD_POSE and res[1]["status"] == hl.STATUS_BAD_POSE
+        assert len(set(res["status"].tolist())) >= 2
+
+
+def test_resolution_and_origin(oracle_built):
+    # 0.5 m cells with a shifted origin: float-accumulated cell axes, non-integer keys
+    p = Pair("map_basic", res=0.5, ox=-3.25, oy=2.5, position_resolution=1, max_iterations=60,
+             vehicle_width=0.5, vehicle_length=1.0, min_turning_radius=2.0, cd_min_turning_radius=2.0)
+    a, b = p.o.obstacles(), p.h.obstacles()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    xyt = p.poses(30000, 71, margin=0.7)
+    pred = (xyt[:, :2] + np.float32(0.07)).astype(np.float32)
+    assert np.array_equal(p.o.collision(xyt, pred), p.h.collision(xyt, pred))
+    s, g = p.free_poses(16, 72), p.free_poses(16, 73)
+    _plan_compare(p, s, g)
