@@ -574,6 +574,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     // no longer than the map diagonal
     m.cull_margin = (float)(0.01 + 2e-3 * std::sqrt((double)w * w + (double)h * h) * res);
     m.pr = c->P.position_resolution, m.headings = c->P.headings;
+    m.twod_size = (uint32_t)c->twod_size;
     m.delta_heading = (float)(2 * HY_PI / (double)(float)c->P.headings); // src/lookup_table.cpp:127
     fill_motion_set(c);
 

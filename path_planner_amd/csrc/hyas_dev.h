@@ -62,7 +62,7 @@ struct DevMap
     // vehicle
     float veh_len, veh_wid;
     double half_wid;     // 0.5 * vehicle_width, src/collisiondetection.cpp:626
-    float cull_margin;   // see seg_quad_may_touch()
+    float cull_margin;   // see seg_hits_quad()
     // heuristic table (dense by reference key; NaN = key never emplaced)
     const float *table;
     uint64_t table_size;
@@ -78,6 +78,7 @@ struct DevMap
     float pen_turn, pen_rev, pen_cod;
     float shot_rho; // params.min_turning_radius
     int32_t curve_type;
+    uint32_t twod_size; // floats per 2D cost map: w*h + w + 1
 };
 
 // ---------------------------------------------------------------- Utility::
@@ -375,18 +376,30 @@ HD bool pose_free(const DevMap &m, float x, float y, float t)
     return true;
 }
 
-// Can GetDistanceFromPolygonToSegment(q, s, e) come out <= half_wid?  Every
-// candidate it takes the minimum over is a point-to-segment distance between
-// the two shapes, except that IsPointOnLine/OnSegment snap distances below
-// about 1e-3 x (edge length) to zero; cull_margin (set by the host from the
-// map diagonal) covers that snap, so a box gap above half_wid + margin proves
-// the test cannot fire.
-HD bool seg_quad_may_touch(const DevMap &m, F2 s, F2 e, const Quad &q)
+// Does GetDistanceFromPolygonToSegment(q, s, e) come out <= half_wid
+// (src/collisiondetection.cpp:626)?  Exact, with a cheap path for far quads.
+// Every candidate the reference takes the minimum over is a point-to-segment
+// distance between the two shapes -- up to the IsPointOnLine/OnSegment snaps,
+// which act within 1e-3 rad / 1e-3 m of an edge and are covered by
+// cull_margin (set by the host from the map diagonal) -- EXCEPT the ray-casting
+// IsInsidePolygon (src/utility.cpp:375-422): its vertex rules can report
+// "inside" (distance -1) for a point far to the LEFT of the quad whose y lies in
+// the quad's y-range.  So when the boxes are more than half_wid + margin apart
+// only that inside test can still fire, and only for such endpoints.
+HD bool seg_hits_quad(const DevMap &m, F2 s, F2 e, const Quad &q)
 {
     const float r = (float)m.half_wid + m.cull_margin;
-    float sxmin = fminf_(s.x, e.x) - r, sxmax = fmaxf_(s.x, e.x) + r;
-    float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
-    return !(q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin);
+    const float sxmin = fminf_(s.x, e.x) - r, sxmax = fmaxf_(s.x, e.x) + r;
+    const float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
+    if (!(q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin))
+        return (double)dist_quad_segment(q, s, e) <= m.half_wid;
+    if (m.half_wid < -1.0)
+        return false; // even "inside" (-1) is not <= half_wid
+    if (s.y >= q.ymin && s.y <= q.ymax && s.x <= q.xmax && inside_quad(q, s))
+        return true;
+    if (e.y >= q.ymin && e.y <= q.ymax && e.x <= q.xmax && inside_quad(q, e))
+        return true;
+    return false;
 }
 
 // src/collisiondetection.cpp:608-656.  true = free.
@@ -399,18 +412,12 @@ HD bool segment_free(const DevMap &m, float sx, float sy, float ex, float ey)
     const uint32_t cells = m.w * m.h;
     if (ks < cells)
         for (uint32_t k = m.cell_off[ks], end = m.cell_off[ks + 1]; k < end; ++k)
-        {
-            const Quad &q = m.quads[m.cell_idx[k]];
-            if (seg_quad_may_touch(m, s, e, q) && (double)dist_quad_segment(q, s, e) <= m.half_wid)
+            if (seg_hits_quad(m, s, e, m.quads[m.cell_idx[k]]))
                 return false;
-        }
     if (ke < cells && ke != ks) // same key: same list, same verdicts
         for (uint32_t k = m.cell_off[ke], end = m.cell_off[ke + 1]; k < end; ++k)
-        {
-            const Quad &q = m.quads[m.cell_idx[k]];
-            if (seg_quad_may_touch(m, s, e, q) && (double)dist_quad_segment(q, s, e) <= m.half_wid)
+            if (seg_hits_quad(m, s, e, m.quads[m.cell_idx[k]]))
                 return false;
-        }
     return true;
 }
 
@@ -483,7 +490,7 @@ HD float heuristic(const DevMap &m, float x, float y, float t, float gx, float g
     if (twod)
     {
         int id = idx_2d(m, x, y);
-        if (id >= 0 && id < (int)(m.w * m.h))
+        if (id >= 0 && id < (int)m.twod_size)
         {
             float v = twod[id];
             if (v >= 0)

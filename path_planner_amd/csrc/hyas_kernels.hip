@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
     const StepIn node = in[slot];
     const bool do_shot = node.shoot != 0; // uniform across the workgroup
     const hyas_goal goal = goals[node.query];
-    const float *my_twod = twod ? twod + (size_t)node.query * m.w * m.h : nullptr;
+    const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
 
     if (wave == 0)
     {
