@@ -221,6 +221,16 @@ int hyas_get_expanded(const hyas_ctx *ctx, size_t i, int32_t *idx, size_t cap);
 double hyas_last_kernel_ms(const hyas_ctx *ctx, int which, int64_t *launches);
 void hyas_reset_kernel_timers(hyas_ctx *ctx);
 
+/* Work counters of the expansion-step kernel, for roofline accounting (no
+ * counterpart in the reference).  hyas_set_stats(ctx, 1) zeroes them and makes
+ * hyas_plan_batch run the instrumented (slower) kernel; hyas_get_stats reads:
+ * 0 curve samples tested, 1 samples a serial scan would test (up to and
+ * including the first colliding one), 2 obstacle-list entries behind (1),
+ * 3 successors that received a verdict, 4 obstacle-list entries behind (3),
+ * 5 successors emitted, 6 nodes expanded, 7 shots evaluated. */
+int hyas_set_stats(hyas_ctx *ctx, int enable);
+int hyas_get_stats(hyas_ctx *ctx, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

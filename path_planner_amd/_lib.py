@@ -65,7 +65,7 @@ EXPORTS = [
     "hyas_collision_batch_dev", "hyas_footprint_table", "hyas_expand_batch", "hyas_num_successors",
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
-    "hyas_last_kernel_ms", "hyas_reset_kernel_timers",
+    "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats",
 ]
 
 _lib = None
@@ -117,6 +117,8 @@ def load_library():
     L.hyas_last_kernel_ms.restype = C.c_double
     L.hyas_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
     L.hyas_reset_kernel_timers.argtypes = [C.c_void_p]
+    L.hyas_set_stats.argtypes = [C.c_void_p, C.c_int]
+    L.hyas_get_stats.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -308,3 +310,13 @@ class Hyas:
 
     def reset_kernel_timers(self):
         self.L.hyas_reset_kernel_timers(self.h)
+
+    def set_stats(self, enable):
+        self._check(self.L.hyas_set_stats(self.h, int(bool(enable))), "hyas_set_stats")
+
+    def stats(self):
+        out = np.zeros(8, np.uint64)
+        self._check(self.L.hyas_get_stats(self.h, _vp(out)), "hyas_get_stats")
+        names = ["samples_tested", "samples_serial", "sample_list_entries", "succ_evaluated", "succ_list_entries",
+                 "succ_emitted", "nodes", "shots"]
+        return dict(zip(names, (int(v) for v in out)))

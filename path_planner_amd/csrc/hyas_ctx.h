@@ -56,7 +56,8 @@ struct hyas_ctx
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double k_ms[5] = {0, 0, 0, 0, 0};
     int64_t k_launches[5] = {0, 0, 0, 0, 0};
-    unsigned long long *d_stats = nullptr; // samples tested by the step kernel
+    unsigned long long *d_stats = nullptr; // 8 work counters of the step kernel
+    bool stats_on = false;
 
     int fail(int code, const std::string &msg)
     {

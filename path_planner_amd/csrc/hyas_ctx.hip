@@ -444,13 +444,13 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     c->P = *params;
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void **)&c->d_stats, sizeof(unsigned long long)) != hipSuccess)
+        hipMalloc((void **)&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess)
     {
         fprintf(stderr, "hyas_create: stream/event creation failed\n");
         delete c;
         return nullptr;
     }
-    (void)hipMemset(c->d_stats, 0, sizeof(unsigned long long));
+    (void)hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long));
     return c;
 }
 
@@ -929,6 +929,25 @@ void hyas_reset_kernel_timers(hyas_ctx *c)
 {
     if (c)
         reset_timers(c);
+}
+
+int hyas_set_stats(hyas_ctx *c, int enable)
+{
+    if (!c)
+        return HYAS_EINVAL;
+    c->stats_on = enable != 0;
+    HYAS_HIP(c, hipSetDevice(c->device));
+    HYAS_HIP(c, hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)));
+    return HYAS_OK;
+}
+
+int hyas_get_stats(hyas_ctx *c, uint64_t out[8])
+{
+    if (!c || !out)
+        return HYAS_EINVAL;
+    HYAS_HIP(c, hipSetDevice(c->device));
+    HYAS_HIP(c, hipMemcpy(out, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HYAS_OK;
 }
 
 // obstacle polygons (8 floats each) and per-key list sizes, for tests

@@ -202,6 +202,29 @@ __device__ __forceinline__ uint32_t count_samples(const double *__restrict__ seg
 // successors with verdict, g, h and index (src/hybrid_a_star.cpp:540-811,
 // :316-366); wave 0 solves the Reeds-Shepp shot to the goal; then all four
 // waves sample the curve (:429-468) until a sample collides.
+// Obstacle-list entries the reference walks for one (pose, predecessor) pair:
+// the list of the cell under polygon[0] plus the lists of both segment ends.
+__device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float y, float t, float px, float py)
+{
+    const uint32_t cells = m.w * m.h;
+    uint32_t n = 0;
+    F2 c[4];
+    vehicle_corners(m, x, y, t, c);
+    uint32_t k0 = grid_key(m, c[0].x, c[0].y), ks = grid_key(m, x, y), ke = grid_key(m, px, py);
+    if (on_grid(m, c[0].x, c[0].y) && k0 < cells)
+        n += m.cell_off[k0 + 1] - m.cell_off[k0];
+    if (on_grid(m, x, y) && ks < cells)
+        n += m.cell_off[ks + 1] - m.cell_off[ks];
+    if (on_grid(m, px, py) && ke < cells)
+        n += m.cell_off[ke + 1] - m.cell_off[ke];
+    return n;
+}
+
+// stats[]: 0 samples tested, 1 samples up to and including the first colliding
+// one (what a serial scan tests), 2 list entries behind (1), 3 successors that
+// received a verdict, 4 list entries behind (3), 5 successors emitted, 6 nodes,
+// 7 shots evaluated.
+template <bool STATS>
 __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
                                                           const hyas_goal *__restrict__ goals,
                                                           const float *__restrict__ twod, // [query][w*h] or null
@@ -213,6 +236,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
     __shared__ rs::Path s_path;
     __shared__ float s_xy[STEP_THREADS][2];
     __shared__ int s_hit;
+    __shared__ unsigned int s_first, s_lists;
     const uint32_t slot = blockIdx.x;
     if (slot >= n)
         return;
@@ -274,6 +298,29 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         }
         if (lane == 0) // low nibble: emitted successors, high nibble: candidates that got a verdict
             count[slot] = (uint8_t)(__popcll(mask) | (__popcll(emask) << 4));
+        if (STATS)
+        {
+            uint32_t walked = 0;
+            if (evaluated)
+            {
+                float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
+                float sx, sy, st;
+                int prim;
+                successor_pose(m, node.x, node.y, node.t, dist, lane, sx, sy, st, prim);
+                walked = lists_walked(m, sx, sy, st, node.x, node.y);
+            }
+            for (int off = 32; off > 0; off >>= 1)
+                walked += __shfl_xor(walked, off, 64);
+            if (lane == 0)
+            {
+                atomicAdd(&stats[3], (unsigned long long)__popcll(emask));
+                atomicAdd(&stats[4], (unsigned long long)walked);
+                atomicAdd(&stats[5], (unsigned long long)__popcll(mask));
+                atomicAdd(&stats[6], 1ull);
+                if (do_shot)
+                    atomicAdd(&stats[7], 1ull);
+            }
+        }
     }
     if (!do_shot)
     {
@@ -293,6 +340,8 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
     unsigned long long tested = 0;
     for (uint32_t base = 0; base < nsamp; base += STEP_THREADS)
     {
+        if (STATS && tid == 0)
+            s_first = 0xFFFFFFFFu, s_lists = 0;
         const uint32_t k = base + tid;
         float x = 0, y = 0, t = 0;
         if (k < nsamp)
@@ -304,16 +353,31 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         s_xy[tid][0] = x, s_xy[tid][1] = y;
         __syncthreads();
         bool hit = false;
+        const float px = tid ? s_xy[tid - 1][0] : prev_x, py = tid ? s_xy[tid - 1][1] : prev_y;
         if (k < nsamp)
         {
-            float px = tid ? s_xy[tid - 1][0] : prev_x, py = tid ? s_xy[tid - 1][1] : prev_y;
             hit = !traversable(m, x, y, t, true, px, py);
             ++tested;
         }
         prev_x = s_xy[STEP_THREADS - 1][0], prev_y = s_xy[STEP_THREADS - 1][1];
         if (hit)
             s_hit = 1;
+        if (STATS && hit)
+            atomicMin(&s_first, k);
         __syncthreads();
+        if (STATS)
+        {
+            const uint32_t first = s_first;
+            if (k < nsamp && k <= first)
+                atomicAdd(&s_lists, lists_walked(m, x, y, t, px, py));
+            __syncthreads();
+            if (tid == 0)
+            {
+                const uint32_t last = (first == 0xFFFFFFFFu) ? ((nsamp - base < STEP_THREADS) ? nsamp - base : STEP_THREADS) : first - base + 1;
+                atomicAdd(&stats[1], (unsigned long long)last);
+                atomicAdd(&stats[2], (unsigned long long)s_lists);
+            }
+        }
         if (s_hit)
         {
             collided = true;
@@ -326,8 +390,8 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         shot_ok[slot] = (!collided && nsamp > 0) ? 1 : 0;
         shot_len[slot] = (float)length;
     }
-    if (stats && tested)
-        atomicAdd(stats, tested);
+    if (STATS && tested)
+        atomicAdd(&stats[0], tested);
 }
 
 // Writes the accepted curve of one query: n samples {x, y, t} (+ the caller
@@ -424,8 +488,13 @@ void launch_step_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_go
                     uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
                     hipStream_t s)
 {
-    if (n)
-        hipLaunchKernelGGL(k_step_rs, dim3(n), dim3(STEP_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
+    if (!n)
+        return;
+    if (stats)
+        hipLaunchKernelGGL(k_step_rs<true>, dim3(n), dim3(STEP_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
+                           count, succ, stats);
+    else
+        hipLaunchKernelGGL(k_step_rs<false>, dim3(n), dim3(STEP_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
                            count, succ, stats);
 }
 

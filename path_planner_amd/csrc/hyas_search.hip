@@ -616,8 +616,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             HYAS_HIP(c, hipMemcpyAsync(ds + o_in, h_in, ns * sizeof(StepIn), hipMemcpyHostToDevice, c->stream));
             timer_begin(c);
             launch_step_rs(m, (const StepIn *)(ds + o_in), (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap,
-                           (uint8_t *)(ds + o_ok), (float *)(ds + o_len), (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), nullptr,
-                           c->stream);
+                           (uint8_t *)(ds + o_ok), (float *)(ds + o_len), (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ),
+                           c->stats_on ? c->d_stats : nullptr, c->stream);
             (void)hipEventRecord(c->ev1, c->stream);
             HYAS_HIP(c, hipMemcpyAsync(hs + o_succ, ds + o_succ, ns * K * sizeof(hyas_succ), hipMemcpyDeviceToHost, c->stream));
             HYAS_HIP(c, hipMemcpyAsync(hs + o_len, ds + o_len, ns * sizeof(float), hipMemcpyDeviceToHost, c->stream));
