@@ -26,8 +26,12 @@
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define HY_HD __host__ __device__ inline
+/* the larger routines are real calls on the device: inlining every sin/cos/
+ * atan2 into a kernel multiplies its code size past the instruction cache */
+#define HY_HD_CALL __host__ __device__ inline __attribute__((noinline))
 #else
 #define HY_HD inline
+#define HY_HD_CALL inline
 #endif
 
 #if defined(__clang__)
@@ -60,7 +64,7 @@ HY_HD float hy_roundf(float x)
 
 /* C fmod: exact remainder with the sign of x.  Long division on the
  * significands; no rounding anywhere. */
-HY_HD double hy_fmod(double x, double y)
+HY_HD_CALL double hy_fmod(double x, double y)
 {
     if (hy_isnan(x) || hy_isnan(y) || y == 0.0 || hy_fabs(x) > 1.7976931348623157e308)
         return (x * y) / (x * y); /* NaN */
@@ -131,7 +135,7 @@ HY_HD double hy_cos_kernel(double r)
     return 1.0 - (0.5 * z - (z * z) * p);
 }
 
-HY_HD double hy_sin(double x)
+HY_HD_CALL double hy_sin(double x)
 {
     int q;
     double r = hy_rem_pio2(x, &q);
@@ -148,7 +152,7 @@ HY_HD double hy_sin(double x)
     }
 }
 
-HY_HD double hy_cos(double x)
+HY_HD_CALL double hy_cos(double x)
 {
     int q;
     double r = hy_rem_pio2(x, &q);
@@ -221,7 +225,7 @@ HY_HD double hy_copysign(double m, double s)
     return __builtin_copysign(m, s);
 }
 
-HY_HD double hy_atan2(double y, double x)
+HY_HD_CALL double hy_atan2(double y, double x)
 {
     if (hy_isnan(x) || hy_isnan(y))
         return x + y;

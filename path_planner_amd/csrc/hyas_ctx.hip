@@ -1,10 +1,12 @@
 // hyas_ctx.hip -- C ABI (include/hyas.h): context life cycle, map ingest,
 // heuristic-table build and the batched kernel entry points.
 #include "hyas_ctx.h"
+#include "hyas_prune.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <queue>
@@ -361,12 +363,14 @@ void flood_2d(const hyas_ctx *c, float gx, float gy, float *out)
 
 static void free_map(hyas_ctx *c)
 {
-    void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg};
+    void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
+                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
     c->d_charmap = nullptr, c->d_quads = nullptr, c->d_cell_off = nullptr, c->d_cell_idx = nullptr, c->d_fp = nullptr;
     c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
+    c->d_pose_off = c->d_seg_off = nullptr, c->d_pose_idx = c->d_seg_idx = nullptr;
     c->have_map = c->have_table = false;
 }
 
@@ -444,13 +448,13 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     c->P = *params;
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void **)&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess)
+        hipMalloc((void **)&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess)
     {
         fprintf(stderr, "hyas_create: stream/event creation failed\n");
         delete c;
         return nullptr;
     }
-    (void)hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long));
+    (void)hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long));
     return c;
 }
 
@@ -582,8 +586,8 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     std::vector<float> xs, ys;
     cell_axes(c, xs, ys);
     extract_obstacles(c, xs, ys);
-    if (c->quads.size() > 65535)
-        return c->fail(HYAS_ERANGE, "more than 65535 obstacle polygons");
+    if (c->quads.size() > 32767)
+        return c->fail(HYAS_ERANGE, "more than 32767 obstacle polygons");
     int rc;
     if ((rc = upload(c, c->d_charmap, c->charmap)) != HYAS_OK)
         return rc;
@@ -633,6 +637,18 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     }
     if ((rc = upload(c, c->d_cell_off, c->cell_off)) != HYAS_OK || (rc = upload(c, c->d_cell_idx, c->cell_idx)) != HYAS_OK)
         return rc;
+    {
+        // successor steps are 0.2 m, curve samples 0.1 x resolution apart
+        const float lmax = std::max(0.3f, 0.2f * (float)res);
+        std::vector<uint32_t> pose_off, seg_off;
+        std::vector<uint16_t> pose_idx, seg_idx;
+        prune_lists(m, c->quads.data(), c->cell_off.data(), c->cell_idx.data(), lmax, pose_off, pose_idx, seg_off, seg_idx);
+        if ((rc = upload(c, c->d_pose_off, pose_off)) != HYAS_OK || (rc = upload(c, c->d_pose_idx, pose_idx)) != HYAS_OK ||
+            (rc = upload(c, c->d_seg_off, seg_off)) != HYAS_OK || (rc = upload(c, c->d_seg_idx, seg_idx)) != HYAS_OK)
+            return rc;
+        m.seg_lmax = std::getenv("HYAS_NO_PRUNE") ? 0.f : lmax;
+        c->n_pose_entries = pose_idx.size(), c->n_seg_entries = seg_idx.size();
+    }
 
     // footprint lists
     fpt::build(c->P, c->fp);
@@ -674,6 +690,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
 
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
     m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx, m.fp = c->d_fp;
+    m.pose_off = c->d_pose_off, m.pose_idx = c->d_pose_idx, m.seg_off = c->d_seg_off, m.seg_idx = c->d_seg_idx;
     m.table = c->d_table, m.table_size = c->table_size;
     m.table_miss = (c->P.curve_type == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
     c->have_map = true;
@@ -937,16 +954,16 @@ int hyas_set_stats(hyas_ctx *c, int enable)
         return HYAS_EINVAL;
     c->stats_on = enable != 0;
     HYAS_HIP(c, hipSetDevice(c->device));
-    HYAS_HIP(c, hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)));
+    HYAS_HIP(c, hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long)));
     return HYAS_OK;
 }
 
-int hyas_get_stats(hyas_ctx *c, uint64_t out[8])
+int hyas_get_stats(hyas_ctx *c, uint64_t out[16])
 {
     if (!c || !out)
         return HYAS_EINVAL;
     HYAS_HIP(c, hipSetDevice(c->device));
-    HYAS_HIP(c, hipMemcpy(out, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HYAS_HIP(c, hipMemcpy(out, c->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HYAS_OK;
 }
 

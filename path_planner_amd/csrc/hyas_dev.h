@@ -13,6 +13,8 @@
 #include "../../include/hyas_math.h"
 
 #define HD __host__ __device__ __forceinline__
+// out-of-line on the device: shared by every call site instead of being copied into each
+#define HDC __host__ __device__ inline __attribute__((noinline))
 
 namespace hyas
 {
@@ -59,6 +61,16 @@ struct DevMap
     uint32_t n_quads;
     const uint32_t *cell_off; // w*h + 1 entries
     const uint16_t *cell_idx;
+    // The same lists with every entry removed that provably cannot change a
+    // verdict (see prune_lists() on the host): pose_* for the vehicle-polygon
+    // test keyed by the cell of corner 0, seg_* for the swept-segment test of
+    // segments no longer than seg_lmax per axis.  Bit 15 of a seg entry: only
+    // the ray-casting inside test can still fire for this quad.
+    const uint32_t *pose_off;
+    const uint16_t *pose_idx;
+    const uint32_t *seg_off;
+    const uint16_t *seg_idx;
+    float seg_lmax; // 0: pruned lists unavailable, walk the full ones
     // vehicle
     float veh_len, veh_wid;
     double half_wid;     // 0.5 * vehicle_width, src/collisiondetection.cpp:626
@@ -86,7 +98,7 @@ struct DevMap
 HD float deg2rad(float deg) { return (float)((double)(deg / 360 * 2) * HY_PI); }
 
 // src/utility.cpp:1249-1268
-HD float rad_0_2pi(float rad)
+HDC float rad_0_2pi(float rad)
 {
     const double two_pi = (double)2.f * HY_PI;
     if ((double)rad >= 0 && (double)rad < two_pi)
@@ -116,7 +128,7 @@ HD float rad_norm(float rad)
 }
 
 // src/utility.cpp:209-249: is q on segment [a, b]?
-HD bool on_segment(F2 a, F2 b, F2 q)
+HDC bool on_segment(F2 a, F2 b, F2 q)
 {
     const bool in_y = q.y <= fmaxf_(a.y, b.y) && q.y >= fminf_(a.y, b.y);
     const bool in_x = q.x <= fmaxf_(a.x, b.x) && q.x >= fminf_(a.x, b.x);
@@ -179,7 +191,7 @@ HD int above_segment(F2 p1, F2 p2, F2 p3)
 }
 
 // src/utility.cpp:375-422: ray casting towards (10000, p.y)
-HD bool inside_quad(const Quad &q, F2 p)
+HDC bool inside_quad(const Quad &q, F2 p)
 {
     F2 far_pt = f2(10000, p.y);
     int crossings = 0;
@@ -225,7 +237,7 @@ HD float dist_point_line(F2 p, F2 start, F2 unit)
 }
 
 // src/utility.cpp:541-576
-HD float dist_seg_point(F2 a, F2 b, F2 p)
+HDC float dist_seg_point(F2 a, F2 b, F2 p)
 {
     if (on_segment(a, b, p))
         return 0;
@@ -241,7 +253,7 @@ HD float dist_seg_point(F2 a, F2 b, F2 p)
 }
 
 // src/utility.cpp:594-619
-HD float dist_quad_point(const Quad &q, F2 p)
+HDC float dist_quad_point(const Quad &q, F2 p)
 {
     for (int i = 0; i < 4; ++i)
         if (on_segment(qv(q, i), qv(q, i + 1), p))
@@ -259,7 +271,7 @@ HD float dist_quad_point(const Quad &q, F2 p)
 }
 
 // src/utility.cpp:967-997
-HD float dist_quad_segment(const Quad &q, F2 s, F2 e)
+HDC float dist_quad_segment(const Quad &q, F2 s, F2 e)
 {
     for (int i = 0; i < 4; ++i)
         if (seg_intersect(qv(q, i), qv(q, i + 1), s, e))
@@ -350,7 +362,7 @@ HD bool vehicle_hits_quad(const F2 c[4], float bxmin, float bymin, float bxmax, 
 }
 
 // src/collisiondetection.cpp:189-214 + :573-606.  true = free.
-HD bool pose_free(const DevMap &m, float x, float y, float t)
+HDC bool pose_free(const DevMap &m, float x, float y, float t)
 {
     uint32_t sx, sy;
     if (!world_to_map(m, x, y, sx, sy))
@@ -370,31 +382,70 @@ HD bool pose_free(const DevMap &m, float x, float y, float t)
     uint32_t key = grid_key(m, c[0].x, c[0].y);
     if (key >= m.w * m.h)
         return true; // key absent from in_range_obstacle_map_: nothing to test
-    for (uint32_t k = m.cell_off[key], e = m.cell_off[key + 1]; k < e; ++k)
-        if (vehicle_hits_quad(c, bxmin, bymin, bxmax, bymax, m.quads[m.cell_idx[k]]))
+    const uint32_t *off = m.seg_lmax > 0 ? m.pose_off : m.cell_off;
+    const uint16_t *idx = m.seg_lmax > 0 ? m.pose_idx : m.cell_idx;
+    for (uint32_t k = off[key], e = off[key + 1]; k < e; ++k)
+        if (vehicle_hits_quad(c, bxmin, bymin, bxmax, bymax, m.quads[idx[k]]))
             return false;
     return true;
 }
 
 // Does GetDistanceFromPolygonToSegment(q, s, e) come out <= half_wid
-// (src/collisiondetection.cpp:626)?  Exact, with a cheap path for far quads.
-// Every candidate the reference takes the minimum over is a point-to-segment
-// distance between the two shapes -- up to the IsPointOnLine/OnSegment snaps,
-// which act within 1e-3 rad / 1e-3 m of an edge and are covered by
-// cull_margin (set by the host from the map diagonal) -- EXCEPT the ray-casting
-// IsInsidePolygon (src/utility.cpp:375-422): its vertex rules can report
-// "inside" (distance -1) for a point far to the LEFT of the quad whose y lies in
-// the quad's y-range.  So when the boxes are more than half_wid + margin apart
-// only that inside test can still fire, and only for such endpoints.
-HD bool seg_hits_quad(const DevMap &m, F2 s, F2 e, const Quad &q)
+// (src/collisiondetection.cpp:626)?  Exact, but evaluated as a predicate.
+//
+// The reference takes the minimum over: -1 if an edge crosses the segment;
+// for each segment end p: 0 if p is on an edge, -1 if the ray-casting
+// IsInsidePolygon says inside, else the distances from p to the four edges; and
+// the distances from the (five, first repeated) vertices to the segment.  The
+// minimum is <= half_wid iff ANY candidate is, so candidates are tested one by
+// one and each is skipped when a box test proves it cannot fire:
+//  * a point-to-edge distance is a true Euclidean distance up to (a) float
+//    rounding, (b) the OnSegment / IsPointOnLine snaps, which turn distances
+//    below 1e-3 m or below 1e-3 rad x (distance to the edge start) into 0, and
+//    (c) cancellation in sqrt(n^2 - proj^2), about 1e-3 / distance.  All are
+//    covered by cull_margin (host: 0.01 + 2e-3 x map diagonal), so a point
+//    outside the edge's box grown by half_wid + cull_margin is farther than
+//    half_wid whatever the reference computes (NaN candidates never count);
+//  * IsInsidePolygon (src/utility.cpp:375-422) can say "inside" for a point far
+//    to the LEFT of the quad when its y lies in the quad's y-range (vertex
+//    rules), so it is evaluated for every such end point, near or far.
+HD bool near_box(F2 p, F2 a, F2 b, float r)
 {
+    return !(p.x < fminf_(a.x, b.x) - r || p.x > fmaxf_(a.x, b.x) + r || p.y < fminf_(a.y, b.y) - r || p.y > fmaxf_(a.y, b.y) + r);
+}
+HDC bool seg_hits_quad(const DevMap &m, F2 s, F2 e, const Quad &q)
+{
+    if (m.half_wid < 0) // the shortcuts below assume 0 <= half_wid
+        return (double)dist_quad_segment(q, s, e) <= m.half_wid;
     const float r = (float)m.half_wid + m.cull_margin;
+    const bool s_ray = s.y >= q.ymin && s.y <= q.ymax && s.x <= q.xmax;
+    const bool e_ray = e.y >= q.ymin && e.y <= q.ymax && e.x <= q.xmax;
+    if (s_ray && inside_quad(q, s))
+        return true;
+    if (e_ray && inside_quad(q, e))
+        return true;
     const float sxmin = fminf_(s.x, e.x) - r, sxmax = fmaxf_(s.x, e.x) + r;
     const float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
-    if (!(q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin))
-        return (double)dist_quad_segment(q, s, e) <= m.half_wid;
-    if (m.half_wid < -1.0)
-        return false; // even "inside" (-1) is not <= half_wid
+    if (q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin)
+        return false;
+    for (int i = 0; i < 4; ++i)
+    {
+        const F2 a = qv(q, i), b = qv(q, i + 1);
+        if (seg_intersect(a, b, s, e))
+            return true;
+        if (near_box(s, a, b, r) && (double)dist_seg_point(a, b, s) <= m.half_wid)
+            return true;
+        if (near_box(e, a, b, r) && (double)dist_seg_point(a, b, e) <= m.half_wid)
+            return true;
+        if (near_box(a, s, e, r) && (double)dist_seg_point(s, e, a) <= m.half_wid)
+            return true;
+    }
+    return false;
+}
+
+// The ray-casting part of seg_hits_quad() alone.
+HDC bool seg_ray_hits_quad(F2 s, F2 e, const Quad &q)
+{
     if (s.y >= q.ymin && s.y <= q.ymax && s.x <= q.xmax && inside_quad(q, s))
         return true;
     if (e.y >= q.ymin && e.y <= q.ymax && e.x <= q.xmax && inside_quad(q, e))
@@ -403,18 +454,36 @@ HD bool seg_hits_quad(const DevMap &m, F2 s, F2 e, const Quad &q)
 }
 
 // src/collisiondetection.cpp:608-656.  true = free.
-HD bool segment_free(const DevMap &m, float sx, float sy, float ex, float ey)
+HDC bool segment_free(const DevMap &m, float sx, float sy, float ex, float ey)
 {
     if (!on_grid(m, sx, sy) || !on_grid(m, ex, ey))
         return false;
     F2 s = f2(sx, sy), e = f2(ex, ey);
     uint32_t ks = grid_key(m, sx, sy), ke = grid_key(m, ex, ey);
     const uint32_t cells = m.w * m.h;
+    if (m.half_wid >= 0 && hy_fabsf(sx - ex) <= m.seg_lmax && hy_fabsf(sy - ey) <= m.seg_lmax)
+    {
+        // short segment: pruned lists
+        for (int pass = 0; pass < 2; ++pass)
+        {
+            const uint32_t key = pass ? ke : ks;
+            if (key >= cells || (pass && ke == ks)) // same key: same list, same verdicts
+                continue;
+            for (uint32_t k = m.seg_off[key], end = m.seg_off[key + 1]; k < end; ++k)
+            {
+                const uint16_t ent = m.seg_idx[k];
+                const Quad &q = m.quads[ent & 0x7fff];
+                if ((ent & 0x8000) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad(m, s, e, q))
+                    return false;
+            }
+        }
+        return true;
+    }
     if (ks < cells)
         for (uint32_t k = m.cell_off[ks], end = m.cell_off[ks + 1]; k < end; ++k)
             if (seg_hits_quad(m, s, e, m.quads[m.cell_idx[k]]))
                 return false;
-    if (ke < cells && ke != ks) // same key: same list, same verdicts
+    if (ke < cells && ke != ks)
         for (uint32_t k = m.cell_off[ke], end = m.cell_off[ke + 1]; k < end; ++k)
             if (seg_hits_quad(m, s, e, m.quads[m.cell_idx[k]]))
                 return false;

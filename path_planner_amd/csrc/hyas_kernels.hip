@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
                                                           hyas_succ *__restrict__ succ, unsigned long long *stats)
 {
     __shared__ rs::Path s_path;
+    __shared__ rs::Prefix s_prefix;
     __shared__ float s_xy[STEP_THREADS][2];
     __shared__ int s_hit;
     __shared__ unsigned int s_first, s_lists;
@@ -243,6 +244,9 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StepIn node = in[slot];
     const bool do_shot = node.shoot != 0; // uniform across the workgroup
+    long long c0 = 0, c1 = 0, c2 = 0;
+    if (STATS)
+        c0 = clock64();
     const hyas_goal goal = goals[node.query];
     const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
 
@@ -256,7 +260,12 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
             rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
             rs::Path p = solve_wave(x, y, phi, lane);
             if (lane == 0)
+            {
                 s_path = p;
+                rs::Prefix pf;
+                rs::build_prefix(p, q0[2], pf);
+                s_prefix = pf;
+            }
         }
         if (lane == 0)
             s_hit = 0;
@@ -329,6 +338,14 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         return;
     }
     __syncthreads();
+    if (STATS)
+    {
+        c1 = clock64();
+        if (tid == 0)
+            atomicAdd(&stats[8], (unsigned long long)(c1 - c0)); // solve + successors
+        if (tid == 64)
+            atomicAdd(&stats[12], (unsigned long long)(c1 - c0));
+    }
 
     const rs::Path path = s_path;
     const double rho = (double)m.shot_rho;
@@ -347,11 +364,17 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         if (k < nsamp)
         {
             double s[3];
-            rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
+            rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
             x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
         }
         s_xy[tid][0] = x, s_xy[tid][1] = y;
         __syncthreads();
+        if (STATS)
+        {
+            c2 = clock64();
+            if (tid == 0)
+                atomicAdd(&stats[9], (unsigned long long)(c2 - c1)), atomicAdd(&stats[11], 1ull); // interpolation, rounds
+        }
         bool hit = false;
         const float px = tid ? s_xy[tid - 1][0] : prev_x, py = tid ? s_xy[tid - 1][1] : prev_y;
         if (k < nsamp)
@@ -365,6 +388,12 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         if (STATS && hit)
             atomicMin(&s_first, k);
         __syncthreads();
+        if (STATS)
+        {
+            c1 = clock64();
+            if (tid == 0)
+                atomicAdd(&stats[10], (unsigned long long)(c1 - c2)); // collision tests of the round
+        }
         if (STATS)
         {
             const uint32_t first = s_first;

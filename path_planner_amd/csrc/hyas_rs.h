@@ -11,6 +11,7 @@
 #include "../../include/hyas_math.h"
 
 #define RS_HD __host__ __device__ __forceinline__
+#define RS_HDC __host__ __device__ inline __attribute__((noinline))
 
 namespace hyas
 {
@@ -41,7 +42,7 @@ RS_HD int seg_kind(int type, int i)
     return (w[type] >> (3 * i)) & 7;
 }
 
-RS_HD double mod2pi(double x) // :50-58
+RS_HDC double mod2pi(double x) // :50-58
 {
     double v = hy_fmod(x, 2. * RS_PI);
     if (v < -RS_PI)
@@ -64,7 +65,7 @@ RS_HD void tau_omega(double u, double v, double xi, double eta, double phi, doub
 }
 
 // The eight base formulas, :73-108, :160-175, :229-260, :312-345, :449-467.
-RS_HD bool base_formula(int f, double x, double y, double phi, double &t, double &u, double &v)
+RS_HDC bool base_formula(int f, double x, double y, double phi, double &t, double &u, double &v)
 {
     const double sp = hy_sin(phi), cp = hy_cos(phi);
     switch (f)
@@ -206,7 +207,7 @@ RS_HD int family_first(int fam)
 // Evaluates candidate c for the normalised goal (x, y, phi).  On success fills
 // p (word, signed lengths, total) and L, the length the family compares
 // (|t|+|u|+|v|, with 2|u| in the CCCC family).
-RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
+RS_HDC bool candidate(int c, double x, double y, double phi, Path &p, double &L)
 {
     int formula, backwards, family, word, layout;
     group_info(c >> 2, formula, backwards, family, word, layout);
@@ -313,7 +314,7 @@ RS_HD void normalise(const double q0[3], const double q1[3], double rho, double 
 }
 
 // State at arc length seg (units of rho) along the path from q0 (:576-625).
-RS_HD void interpolate(const double q0[3], const Path &path, double seg, double rho, double s[3])
+RS_HDC void interpolate(const double q0[3], const Path &path, double seg, double rho, double s[3])
 {
     if (seg < 0.0)
         seg = 0.0;
@@ -357,6 +358,104 @@ RS_HD void interpolate(const double q0[3], const Path &path, double seg, double 
     }
     s[0] = s[0] * rho + q0[0];
     s[1] = s[1] * rho + q0[1];
+}
+
+// ---- sampling many points of one path ------------------------------------
+// interpolate() walks the segments in order and adds each one's increment to
+// (x, y, phi).  For a point inside segment j the increments of segments 0..j-1
+// are those of the complete segments, identical for every such point, so they
+// are accumulated once (same operations, same order) and a sample only adds
+// its own partial increment: two sin/cos instead of up to twenty.
+struct Prefix
+{
+    double x[6], y[6], phi[6]; // state in front of segment i (units of rho, origin at q0)
+    double s[5], c[5];         // sin(phi[i]), cos(phi[i])
+};
+
+RS_HDC void build_prefix(const Path &path, double phi0, Prefix &P)
+{
+    P.x[0] = 0.0, P.y[0] = 0.0, P.phi[0] = phi0;
+    for (int i = 0; i < 5; ++i)
+    {
+        const double phi = P.phi[i], v = path.len[i];
+        const double sp = hy_sin(phi), cp = hy_cos(phi);
+        P.s[i] = sp, P.c[i] = cp;
+        double x = P.x[i], y = P.y[i], nphi = phi;
+        const int kind = seg_kind(path.type, i);
+        if (kind == 1)
+        {
+            x += (hy_sin(phi + v) - sp);
+            y += (-hy_cos(phi + v) + cp);
+            nphi = phi + v;
+        }
+        else if (kind == 3)
+        {
+            x += (-hy_sin(phi - v) + sp);
+            y += (hy_cos(phi - v) - cp);
+            nphi = phi - v;
+        }
+        else if (kind == 2)
+        {
+            x += (v * cp);
+            y += (v * sp);
+        }
+        P.x[i + 1] = x, P.y[i + 1] = y, P.phi[i + 1] = nphi;
+    }
+}
+
+// Same result as interpolate(q0, path, seg, rho, s), bit for bit.
+RS_HDC void interpolate_prefix(const double q0[3], const Path &path, const Prefix &P, double seg, double rho, double s[3])
+{
+    if (seg < 0.0)
+        seg = 0.0;
+    if (seg > path.total)
+        seg = path.total;
+    double x = 0.0, y = 0.0, phi = q0[2];
+    for (int i = 0; i < 5 && seg > 0; ++i)
+    {
+        const double li = path.len[i];
+        double v;
+        if (li < 0)
+        {
+            v = (-seg < li) ? li : -seg;
+            seg += v;
+        }
+        else
+        {
+            v = (li < seg) ? li : seg;
+            seg -= v;
+        }
+        if (v == li)
+        { // the whole segment: its increment is the shared one
+            x = P.x[i + 1], y = P.y[i + 1], phi = P.phi[i + 1];
+            continue;
+        }
+        const double p0 = P.phi[i];
+        const int kind = seg_kind(path.type, i);
+        if (kind == 1)
+        {
+            x = P.x[i] + (hy_sin(p0 + v) - P.s[i]);
+            y = P.y[i] + (-hy_cos(p0 + v) + P.c[i]);
+            phi = p0 + v;
+        }
+        else if (kind == 3)
+        {
+            x = P.x[i] + (-hy_sin(p0 - v) + P.s[i]);
+            y = P.y[i] + (hy_cos(p0 - v) - P.c[i]);
+            phi = p0 - v;
+        }
+        else if (kind == 2)
+        {
+            x = P.x[i] + (v * P.c[i]);
+            y = P.y[i] + (v * P.s[i]);
+            phi = p0;
+        }
+        else
+            x = P.x[i], y = P.y[i], phi = p0;
+    }
+    s[0] = x * rho + q0[0];
+    s[1] = y * rho + q0[1];
+    s[2] = phi;
 }
 
 } // namespace rs
