@@ -227,11 +227,11 @@ void hyas_reset_kernel_timers(hyas_ctx *ctx);
  * 0 curve samples tested, 1 samples a serial scan would test (up to and
  * including the first colliding one), 2 obstacle-list entries behind (1),
  * 3 successors that received a verdict, 4 obstacle-list entries behind (3),
- * 5 successors emitted, 6 nodes expanded, 7 shots evaluated; 8..12 shader
- * clock sums per phase (curve solve + successors, sample interpolation,
- * sample collision tests, number of sample rounds, successor wave). */
+ * 5 successors emitted, 6 nodes expanded, 7 shots evaluated; 8..10 shader
+ * clock sums (curve solve + successors, sample interpolation, sample collision
+ * tests), 11..15 the five waves' share of the first, 16 sample rounds. */
 int hyas_set_stats(hyas_ctx *ctx, int enable);
-int hyas_get_stats(hyas_ctx *ctx, uint64_t out[16]);
+int hyas_get_stats(hyas_ctx *ctx, uint64_t out[24]);
 
 #ifdef __cplusplus
 }

@@ -315,9 +315,9 @@ class Hyas:
         self._check(self.L.hyas_set_stats(self.h, int(bool(enable))), "hyas_set_stats")
 
     def stats(self):
-        out = np.zeros(16, np.uint64)
+        out = np.zeros(24, np.uint64)
         self._check(self.L.hyas_get_stats(self.h, _vp(out)), "hyas_get_stats")
         names = ["samples_tested", "samples_serial", "sample_list_entries", "succ_evaluated", "succ_list_entries",
-                 "succ_emitted", "nodes", "shots", "clk_solve", "clk_interp", "clk_collide", "rounds", "clk_succ_wave",
-                 "r13", "r14", "r15"]
+                 "succ_emitted", "nodes", "shots", "clk_solve", "clk_interp", "clk_collide", "clk_w0", "clk_w1",
+                 "clk_w2", "clk_w3", "clk_w4", "rounds"]
         return dict(zip(names, (int(v) for v in out)))

@@ -99,6 +99,11 @@ static Quad make_quad(const float vx[4], const float vy[4])
         q.vx[i] = vx[i], q.vy[i] = vy[i];
     q.xmin = *std::min_element(vx, vx + 4), q.xmax = *std::max_element(vx, vx + 4);
     q.ymin = *std::min_element(vy, vy + 4), q.ymax = *std::max_element(vy, vy + 4);
+    q.axis_rect = (vx[0] == q.xmin && vy[0] == q.ymin && vx[1] == q.xmax && vy[1] == q.ymin && vx[2] == q.xmax && vy[2] == q.ymax &&
+                   vx[3] == q.xmin && vy[3] == q.ymax && q.xmin < q.xmax && q.ymin < q.ymax)
+                      ? 1u
+                      : 0u;
+    q.pad[0] = q.pad[1] = q.pad[2] = 0;
     return q;
 }
 
@@ -361,6 +366,17 @@ void flood_2d(const hyas_ctx *c, float gx, float gy, float *out)
     }
 }
 
+static void set_resolution(DevMap &m, double res, double ox, double oy)
+{
+    m.res = res, m.ox = ox, m.oy = oy;
+    m.res_f = (float)res, m.ox_f = (float)ox, m.oy_f = (float)oy; // src/collisiondetection.cpp:13-15
+    int e = 0;
+    const bool p2 = std::frexp(res, &e) == 0.5 && e > -60 && e < 60 && (double)m.res_f == res;
+    m.res_pow2 = p2 ? 1 : 0;
+    m.inv_res = p2 ? 1.0 / res : 0.0;
+    m.inv_res_f = p2 ? (float)(1.0 / res) : 0.f;
+}
+
 static void free_map(hyas_ctx *c)
 {
     void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
@@ -417,6 +433,8 @@ static bool params_ok(const hyas_params *p, std::string &why)
         why = "headings / position_resolution out of range";
     else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS)
         why = "curve_type must be 0 (Dubins) or 1 (Reeds-Shepp)";
+    else if (!(p->vehicle_width >= 0) || !(p->vehicle_length >= 0))
+        why = "vehicle dimensions must not be negative";
     else if (!(p->min_turning_radius > 0) || !(p->cd_min_turning_radius > 0))
         why = "turning radius must be positive";
     else if (p->number_of_successors < 1 || 1 + 2 * ((p->number_of_successors - 1) / 2) + (p->reverse ? 1 : 0) > HYAS_MAX_SUCC)
@@ -448,13 +466,13 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     c->P = *params;
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void **)&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess)
+        hipMalloc((void **)&c->d_stats, 24 * sizeof(unsigned long long)) != hipSuccess)
     {
         fprintf(stderr, "hyas_create: stream/event creation failed\n");
         delete c;
         return nullptr;
     }
-    (void)hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long));
+    (void)hipMemset(c->d_stats, 0, 24 * sizeof(unsigned long long));
     return c;
 }
 
@@ -570,8 +588,8 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
 
     DevMap &m = c->dm;
     m = DevMap{};
-    m.w = w, m.h = h, m.res = res, m.ox = ox, m.oy = oy;
-    m.res_f = (float)res, m.ox_f = (float)ox, m.oy_f = (float)oy; // src/collisiondetection.cpp:13-15
+    m.w = w, m.h = h;
+    set_resolution(m, res, ox, oy);
     m.veh_len = c->P.vehicle_length, m.veh_wid = c->P.vehicle_width;
     m.half_wid = 0.5 * (double)c->P.vehicle_width;
     // the on-line / on-segment snaps act within 1e-3 rad or 1e-3 m of an edge
@@ -729,7 +747,8 @@ int hyas_set_grid(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h)
     c->twod_size = 0;
     DevMap &m = c->dm;
     m = DevMap{};
-    m.w = w, m.h = h, m.res = 1, m.ox = 0, m.oy = 0, m.res_f = 1, m.ox_f = 0, m.oy_f = 0;
+    m.w = w, m.h = h;
+    set_resolution(m, 1.0, 0.0, 0.0);
     m.pr = c->P.position_resolution, m.headings = c->P.headings;
     m.delta_heading = (float)(2 * HY_PI / (double)(float)c->P.headings);
     int rc;
@@ -954,16 +973,16 @@ int hyas_set_stats(hyas_ctx *c, int enable)
         return HYAS_EINVAL;
     c->stats_on = enable != 0;
     HYAS_HIP(c, hipSetDevice(c->device));
-    HYAS_HIP(c, hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long)));
+    HYAS_HIP(c, hipMemset(c->d_stats, 0, 24 * sizeof(unsigned long long)));
     return HYAS_OK;
 }
 
-int hyas_get_stats(hyas_ctx *c, uint64_t out[16])
+int hyas_get_stats(hyas_ctx *c, uint64_t out[24])
 {
     if (!c || !out)
         return HYAS_EINVAL;
     HYAS_HIP(c, hipSetDevice(c->device));
-    HYAS_HIP(c, hipMemcpy(out, c->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HYAS_HIP(c, hipMemcpy(out, c->d_stats, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HYAS_OK;
 }
 

@@ -44,6 +44,10 @@ struct Quad
 {
     float vx[4], vy[4];
     float xmin, ymin, xmax, ymax;
+    // 1: the vertices are exactly (xmin,ymin) (xmax,ymin) (xmax,ymax) (xmin,ymax)
+    // in this order -- what CreatePolygon(origin, w, h) and vertical merges produce
+    uint32_t axis_rect;
+    uint32_t pad[3];
 };
 HD F2 qv(const Quad &q, int i) { return f2(q.vx[i & 3], q.vy[i & 3]); }
 
@@ -56,6 +60,11 @@ struct DevMap
     double res, ox, oy;
     // CollisionDetection members (float)
     float res_f, ox_f, oy_f;
+    // resolution a power of two: dividing by it equals multiplying by its
+    // (exact) inverse, bit for bit, and the division can be skipped
+    int32_t res_pow2;
+    double inv_res;
+    float inv_res_f;
     // obstacles and per-grid-key lists (key = GetNode3DIndexOnGridMap)
     const Quad *quads;
     uint32_t n_quads;
@@ -98,7 +107,7 @@ struct DevMap
 HD float deg2rad(float deg) { return (float)((double)(deg / 360 * 2) * HY_PI); }
 
 // src/utility.cpp:1249-1268
-HDC float rad_0_2pi(float rad)
+HD float rad_0_2pi(float rad)
 {
     const double two_pi = (double)2.f * HY_PI;
     if ((double)rad >= 0 && (double)rad < two_pi)
@@ -128,7 +137,7 @@ HD float rad_norm(float rad)
 }
 
 // src/utility.cpp:209-249: is q on segment [a, b]?
-HDC bool on_segment(F2 a, F2 b, F2 q)
+HD bool on_segment(F2 a, F2 b, F2 q)
 {
     const bool in_y = q.y <= fmaxf_(a.y, b.y) && q.y >= fminf_(a.y, b.y);
     const bool in_x = q.x <= fmaxf_(a.x, b.x) && q.x >= fminf_(a.x, b.x);
@@ -191,10 +200,11 @@ HD int above_segment(F2 p1, F2 p2, F2 p3)
 }
 
 // src/utility.cpp:375-422: ray casting towards (10000, p.y)
-HDC bool inside_quad(const Quad &q, F2 p)
+HDC bool inside_quad(Quad q, F2 p)
 {
     F2 far_pt = f2(10000, p.y);
     int crossings = 0;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
     {
         F2 a = qv(q, i), b = qv(q, i + 1);
@@ -300,8 +310,16 @@ HD bool world_to_map(const DevMap &m, float wx, float wy, uint32_t &mx, uint32_t
     double x = (double)wx, y = (double)wy;
     if (x < m.ox || y < m.oy)
         return false;
-    mx = (uint32_t)(int)((x - m.ox) / m.res);
-    my = (uint32_t)(int)((y - m.oy) / m.res);
+    if (m.res_pow2)
+    {
+        mx = (uint32_t)(int)((x - m.ox) * m.inv_res);
+        my = (uint32_t)(int)((y - m.oy) * m.inv_res);
+    }
+    else
+    {
+        mx = (uint32_t)(int)((x - m.ox) / m.res);
+        my = (uint32_t)(int)((y - m.oy) / m.res);
+    }
     return mx < m.w && my < m.h;
 }
 HD bool on_grid(const DevMap &m, float x, float y)
@@ -313,22 +331,27 @@ HD bool on_grid(const DevMap &m, float x, float y)
 // floor(round(v*1000)/1000), the index rounding of include/node3d.h:67
 HD float idx_round(float v) { return hy_floorf(hy_roundf(v * 1000) / 1000); }
 
+// (v - origin) / resolution in float
+HD float cell_coord(const DevMap &m, float v, float origin)
+{
+    return m.res_pow2 ? (v - origin) * m.inv_res_f : (v - origin) / m.res_f;
+}
 // src/collisiondetection.cpp:362-369
 HD uint32_t grid_key(const DevMap &m, float x, float y)
 {
-    return (uint32_t)(idx_round((y - m.oy_f) / m.res_f) * m.w + idx_round((x - m.ox_f) / m.res_f));
+    return (uint32_t)(idx_round(cell_coord(m, y, m.oy_f)) * m.w + idx_round(cell_coord(m, x, m.ox_f)));
 }
 // include/node2d.h:59-66
 HD int idx_2d(const DevMap &m, float x, float y)
 {
-    return (int)(idx_round((y - m.oy_f) / m.res_f) * (int)m.w + idx_round((x - m.ox_f) / m.res_f));
+    return (int)(idx_round(cell_coord(m, y, m.oy_f)) * (int)m.w + idx_round(cell_coord(m, x, m.ox_f)));
 }
 // include/node3d.h:65-72 with delta = (float)((float)2*M_PI/headings)
 HD int idx_3d(const DevMap &m, float x, float y, float t)
 {
     const float delta = (float)((double)(float)2 * HY_PI / m.headings);
-    return (int)(idx_round(t / delta) * (int)m.w * (int)m.h + idx_round((y - m.oy_f) / m.res_f) * (int)m.w +
-                 idx_round((x - m.ox_f) / m.res_f));
+    return (int)(idx_round(t / delta) * (int)m.w * (int)m.h + idx_round(cell_coord(m, y, m.oy_f)) * (int)m.w +
+                 idx_round(cell_coord(m, x, m.ox_f)));
 }
 
 // -------------------------------------------------- collision, polygon mode
@@ -344,16 +367,26 @@ HD void vehicle_corners(const DevMap &m, float x, float y, float t, F2 c[4])
         c[i] = f2(x + (ct * px[i] + m01 * py[i]), y + (st * px[i] + ct * py[i]));
 }
 
+// Where the kernels read obstacle quads from: global memory (default) or a
+// workgroup-local copy.  Fetch returns the quad by value so the out-of-line
+// geometry routines below work on registers, not on pointers.
+struct GlobalQuads
+{
+    const Quad *p;
+    HD Quad operator()(uint32_t i) const { return p[i]; }
+};
+
 // src/utility.cpp:956-966 + :528-540 for a 4-corner vehicle against one quad.
 // The bounding-box test is exact: when the boxes are strictly apart every
 // edge pair fails IsIntersect's own box test.
-HD bool vehicle_hits_quad(const F2 c[4], float bxmin, float bymin, float bxmax, float bymax, const Quad &q)
+HDC bool vehicle_hits_quad(F2 c0, F2 c1, F2 c2, F2 c3, Quad q)
 {
-    if (q.xmax < bxmin || q.ymax < bymin || bxmax < q.xmin || bymax < q.ymin)
-        return false;
+    const F2 c[4] = {c0, c1, c2, c3};
+#pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        F2 a = c[i], b = c[(i + 1) & 3];
+        const F2 a = c[i], b = c[(i + 1) & 3];
+#pragma unroll
         for (int j = 0; j < 4; ++j)
             if (seg_intersect(qv(q, j), qv(q, j + 1), a, b))
                 return true;
@@ -362,7 +395,8 @@ HD bool vehicle_hits_quad(const F2 c[4], float bxmin, float bymin, float bxmax, 
 }
 
 // src/collisiondetection.cpp:189-214 + :573-606.  true = free.
-HDC bool pose_free(const DevMap &m, float x, float y, float t)
+template <class QuadSrc>
+HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float t)
 {
     uint32_t sx, sy;
     if (!world_to_map(m, x, y, sx, sy))
@@ -372,6 +406,7 @@ HDC bool pose_free(const DevMap &m, float x, float y, float t)
     F2 c[4];
     vehicle_corners(m, x, y, t, c);
     float bxmin = c[0].x, bxmax = c[0].x, bymin = c[0].y, bymax = c[0].y;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
     {
         if (!on_grid(m, c[i].x, c[i].y))
@@ -384,10 +419,36 @@ HDC bool pose_free(const DevMap &m, float x, float y, float t)
         return true; // key absent from in_range_obstacle_map_: nothing to test
     const uint32_t *off = m.seg_lmax > 0 ? m.pose_off : m.cell_off;
     const uint16_t *idx = m.seg_lmax > 0 ? m.pose_idx : m.cell_idx;
+#pragma unroll 1
     for (uint32_t k = off[key], e = off[key + 1]; k < e; ++k)
-        if (vehicle_hits_quad(c, bxmin, bymin, bxmax, bymax, m.quads[idx[k]]))
+    {
+        const Quad q = quads(idx[k]);
+        if (q.xmax < bxmin || q.ymax < bymin || bxmax < q.xmin || bymax < q.ymin)
+            continue;
+        if (vehicle_hits_quad(c[0], c[1], c[2], c[3], q))
             return false;
+    }
     return true;
+}
+
+// inside_quad() for a point already known to have q.ymin <= p.y <= q.ymax and
+// p.x <= q.xmax.  For an axis-aligned rectangle and a point whose y is more
+// than 2e-3 away from both horizontal edges the ray to (10000, p.y) meets the
+// two horizontal edges nowhere (their box test fails) and each vertical edge
+// right of p exactly once, away from the vertices (the vertex rules of
+// src/utility.cpp:387-402 act within 1e-3): the count is 2 left of the
+// rectangle and 1 inside it.  Within 1e-2 of a vertical edge the exact routine
+// decides.  Returns 0 outside, 1 inside, -1 undecided.
+HD int inside_quad_fast(const Quad &q, F2 p)
+{
+    if (q.axis_rect && p.y > q.ymin + 2e-3f && p.y < q.ymax - 2e-3f)
+    {
+        if (p.x < q.xmin - 1e-2f)
+            return 0;
+        if (p.x > q.xmin + 1e-2f && p.x < q.xmax - 1e-2f)
+            return 1;
+    }
+    return -1;
 }
 
 // Does GetDistanceFromPolygonToSegment(q, s, e) come out <= half_wid
@@ -409,95 +470,98 @@ HDC bool pose_free(const DevMap &m, float x, float y, float t)
 //  * IsInsidePolygon (src/utility.cpp:375-422) can say "inside" for a point far
 //    to the LEFT of the quad when its y lies in the quad's y-range (vertex
 //    rules), so it is evaluated for every such end point, near or far.
+// Assumes 0 <= half_wid (hyas_create rejects a negative vehicle width).
 HD bool near_box(F2 p, F2 a, F2 b, float r)
 {
     return !(p.x < fminf_(a.x, b.x) - r || p.x > fmaxf_(a.x, b.x) + r || p.y < fminf_(a.y, b.y) - r || p.y > fmaxf_(a.y, b.y) + r);
 }
-HDC bool seg_hits_quad(const DevMap &m, F2 s, F2 e, const Quad &q)
+// the edge part: the quad's box is within r of the segment's box
+HDC bool seg_hits_quad_near(float r, double half_wid, F2 s, F2 e, Quad q)
 {
-    if (m.half_wid < 0) // the shortcuts below assume 0 <= half_wid
-        return (double)dist_quad_segment(q, s, e) <= m.half_wid;
-    const float r = (float)m.half_wid + m.cull_margin;
-    const bool s_ray = s.y >= q.ymin && s.y <= q.ymax && s.x <= q.xmax;
-    const bool e_ray = e.y >= q.ymin && e.y <= q.ymax && e.x <= q.xmax;
-    if (s_ray && inside_quad(q, s))
-        return true;
-    if (e_ray && inside_quad(q, e))
-        return true;
-    const float sxmin = fminf_(s.x, e.x) - r, sxmax = fmaxf_(s.x, e.x) + r;
-    const float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
-    if (q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin)
-        return false;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
     {
         const F2 a = qv(q, i), b = qv(q, i + 1);
         if (seg_intersect(a, b, s, e))
             return true;
-        if (near_box(s, a, b, r) && (double)dist_seg_point(a, b, s) <= m.half_wid)
+        if (near_box(s, a, b, r) && (double)dist_seg_point(a, b, s) <= half_wid)
             return true;
-        if (near_box(e, a, b, r) && (double)dist_seg_point(a, b, e) <= m.half_wid)
+        if (near_box(e, a, b, r) && (double)dist_seg_point(a, b, e) <= half_wid)
             return true;
-        if (near_box(a, s, e, r) && (double)dist_seg_point(s, e, a) <= m.half_wid)
+        if (near_box(a, s, e, r) && (double)dist_seg_point(s, e, a) <= half_wid)
             return true;
     }
     return false;
 }
-
-// The ray-casting part of seg_hits_quad() alone.
-HDC bool seg_ray_hits_quad(F2 s, F2 e, const Quad &q)
+// the ray-casting part
+HD bool seg_ray_hits_quad(F2 s, F2 e, const Quad &q)
 {
-    if (s.y >= q.ymin && s.y <= q.ymax && s.x <= q.xmax && inside_quad(q, s))
-        return true;
-    if (e.y >= q.ymin && e.y <= q.ymax && e.x <= q.xmax && inside_quad(q, e))
-        return true;
+    if (s.y >= q.ymin && s.y <= q.ymax && s.x <= q.xmax)
+    {
+        int f = inside_quad_fast(q, s);
+        if (f > 0 || (f < 0 && inside_quad(q, s)))
+            return true;
+    }
+    if (e.y >= q.ymin && e.y <= q.ymax && e.x <= q.xmax)
+    {
+        int f = inside_quad_fast(q, e);
+        if (f > 0 || (f < 0 && inside_quad(q, e)))
+            return true;
+    }
     return false;
+}
+HD bool seg_hits_quad(float r, double half_wid, F2 s, F2 e, const Quad &q)
+{
+    if (seg_ray_hits_quad(s, e, q))
+        return true;
+    const float sxmin = fminf_(s.x, e.x) - r, sxmax = fmaxf_(s.x, e.x) + r;
+    const float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
+    if (q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin)
+        return false;
+    return seg_hits_quad_near(r, half_wid, s, e, q);
 }
 
 // src/collisiondetection.cpp:608-656.  true = free.
-HDC bool segment_free(const DevMap &m, float sx, float sy, float ex, float ey)
+template <class QuadSrc>
+HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, float ex, float ey)
 {
     if (!on_grid(m, sx, sy) || !on_grid(m, ex, ey))
         return false;
-    F2 s = f2(sx, sy), e = f2(ex, ey);
-    uint32_t ks = grid_key(m, sx, sy), ke = grid_key(m, ex, ey);
+    const F2 s = f2(sx, sy), e = f2(ex, ey);
+    const uint32_t ks = grid_key(m, sx, sy), ke = grid_key(m, ex, ey);
     const uint32_t cells = m.w * m.h;
-    if (m.half_wid >= 0 && hy_fabsf(sx - ex) <= m.seg_lmax && hy_fabsf(sy - ey) <= m.seg_lmax)
+    const float r = (float)m.half_wid + m.cull_margin;
+    const bool pruned = hy_fabsf(sx - ex) <= m.seg_lmax && hy_fabsf(sy - ey) <= m.seg_lmax;
+    const uint32_t *off = pruned ? m.seg_off : m.cell_off;
+    const uint16_t *idx = pruned ? m.seg_idx : m.cell_idx;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass)
     {
-        // short segment: pruned lists
-        for (int pass = 0; pass < 2; ++pass)
+        const uint32_t key = pass ? ke : ks;
+        if (key >= cells || (pass && ke == ks)) // same key: same list, same verdicts
+            continue;
+#pragma unroll 1
+        for (uint32_t k = off[key], end = off[key + 1]; k < end; ++k)
         {
-            const uint32_t key = pass ? ke : ks;
-            if (key >= cells || (pass && ke == ks)) // same key: same list, same verdicts
-                continue;
-            for (uint32_t k = m.seg_off[key], end = m.seg_off[key + 1]; k < end; ++k)
-            {
-                const uint16_t ent = m.seg_idx[k];
-                const Quad &q = m.quads[ent & 0x7fff];
-                if ((ent & 0x8000) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad(m, s, e, q))
-                    return false;
-            }
+            const uint16_t ent = idx[k];
+            const Quad q = quads(ent & 0x7fffu);
+            // bit 15 (pruned lists only): only the ray-casting test can fire
+            if ((pruned && (ent & 0x8000u)) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad(r, m.half_wid, s, e, q))
+                return false;
         }
-        return true;
     }
-    if (ks < cells)
-        for (uint32_t k = m.cell_off[ks], end = m.cell_off[ks + 1]; k < end; ++k)
-            if (seg_hits_quad(m, s, e, m.quads[m.cell_idx[k]]))
-                return false;
-    if (ke < cells && ke != ks)
-        for (uint32_t k = m.cell_off[ke], end = m.cell_off[ke + 1]; k < end; ++k)
-            if (seg_hits_quad(m, s, e, m.quads[m.cell_idx[k]]))
-                return false;
     return true;
 }
 
 // src/collisiondetection.cpp:93-127
-HD bool traversable(const DevMap &m, float x, float y, float t, bool has_pred, float px, float py)
+template <class QuadSrc>
+HD bool traversable(const DevMap &m, const QuadSrc &quads, float x, float y, float t, bool has_pred, float px, float py)
 {
     if (!on_grid(m, x, y))
         return false;
-    if (!pose_free(m, x, y, t))
+    if (!pose_free(m, quads, x, y, t))
         return false;
-    return has_pred ? segment_free(m, x, y, px, py) : true;
+    return has_pred ? segment_free(m, quads, x, y, px, py) : true;
 }
 
 // ------------------------------------------------ collision, footprint mode

@@ -24,7 +24,8 @@ __global__ void __launch_bounds__(256) k_collision_polygon(DevMap m, const float
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     {
         float x = xyt[3 * i], y = xyt[3 * i + 1], t = xyt[3 * i + 2];
-        bool ok = pred_xy ? traversable(m, x, y, t, true, pred_xy[2 * i], pred_xy[2 * i + 1]) : traversable(m, x, y, t, false, 0, 0);
+        const GlobalQuads gq{m.quads};
+        bool ok = pred_xy ? traversable(m, gq, x, y, t, true, pred_xy[2 * i], pred_xy[2 * i + 1]) : traversable(m, gq, x, y, t, false, 0, 0);
         out[i] = ok ? 1 : 0;
     }
 }
@@ -196,12 +197,97 @@ __device__ __forceinline__ uint32_t count_samples(const double *__restrict__ seg
     return lo;
 }
 
-#define STEP_THREADS 256
+#define STEP_THREADS 320 // five waves
+#define STEP_LDS_QUADS 192 // obstacle quads kept in LDS (12 KB)
 
-// One workgroup per popped node.  Wave 1 generates the motion-primitive
-// successors with verdict, g, h and index (src/hybrid_a_star.cpp:540-811,
-// :316-366); wave 0 solves the Reeds-Shepp shot to the goal; then all four
-// waves sample the curve (:429-468) until a sample collides.
+// Quads from the workgroup's LDS copy when there is one, else from global memory.
+struct StepQuads
+{
+    const Quad *lds; // null: no local copy
+    const Quad *glb;
+    __device__ __forceinline__ Quad operator()(uint32_t i) const { return lds ? lds[i] : glb[i]; }
+};
+#ifndef STEP_MIN_WAVES
+#define STEP_MIN_WAVES 4 // waves per SIMD the register allocation must allow: three workgroups per CU
+#endif
+
+struct CandOut
+{
+    rs::Path p;
+    double L;
+    int valid;
+};
+
+// Reduces the 44 evaluated candidates (one per lane, lanes >= 44 invalid) in
+// reference order; every lane returns the winning path.
+__device__ __forceinline__ rs::Path reduce_candidates(const rs::Path &mine, double L, bool valid, int lane)
+{
+    const double inf = __builtin_huge_val();
+    rs::Path best = rs::empty_path();
+    for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
+    {
+        const bool in_fam = lane >= rs::family_first(fam) && lane < rs::family_first(fam + 1);
+        const double key = (valid && in_fam && L == L) ? L : inf;
+        const double mn = wave_min(key);
+        const double bound = rs::family_bound(fam, best.total);
+        if (bound > mn) // uniform across the wave
+        {
+            unsigned long long who = __ballot(key == mn);
+            int src = __ffsll((long long)who) - 1;
+            best.type = __shfl(mine.type, src, 64);
+            for (int i = 0; i < 5; ++i)
+                best.len[i] = __shfl(mine.len[i], src, 64);
+            best.total = __shfl(mine.total, src, 64);
+        }
+    }
+    return best;
+}
+
+// rs::build_prefix with the six heading sin/cos pairs evaluated on six lanes.
+// Every lane of the wave must call it; every lane returns the full prefix.
+__device__ __forceinline__ void build_prefix_wave(const rs::Path &path, double phi0, int lane, rs::Prefix &P)
+{
+    double phi[6];
+    phi[0] = phi0;
+    for (int i = 0; i < 5; ++i)
+    {
+        const int kind = rs::seg_kind(path.type, i);
+        phi[i + 1] = (kind == 1) ? phi[i] + path.len[i] : (kind == 3) ? phi[i] - path.len[i] : phi[i];
+    }
+    double my_phi = phi[0];
+    for (int i = 1; i < 6; ++i)
+        my_phi = (lane == i) ? phi[i] : my_phi;
+    const double my_s = hy_sin(my_phi), my_c = hy_cos(my_phi);
+    double sn[6], cs[6];
+    for (int i = 0; i < 6; ++i)
+        sn[i] = __shfl(my_s, i, 64), cs[i] = __shfl(my_c, i, 64);
+    P.x[0] = 0.0, P.y[0] = 0.0;
+    for (int i = 0; i < 5; ++i)
+    {
+        const int kind = rs::seg_kind(path.type, i);
+        const double v = path.len[i];
+        double x = P.x[i], y = P.y[i];
+        if (kind == 1)
+        {
+            x += (sn[i + 1] - sn[i]);
+            y += (-cs[i + 1] + cs[i]);
+        }
+        else if (kind == 3)
+        {
+            x += (-sn[i + 1] + sn[i]);
+            y += (cs[i + 1] - cs[i]);
+        }
+        else if (kind == 2)
+        {
+            x += (v * cs[i]);
+            y += (v * sn[i]);
+        }
+        P.x[i + 1] = x, P.y[i + 1] = y;
+        P.phi[i] = phi[i], P.s[i] = sn[i], P.c[i] = cs[i];
+    }
+    P.phi[5] = phi[5];
+}
+
 // Obstacle-list entries the reference walks for one (pose, predecessor) pair:
 // the list of the cell under polygon[0] plus the lists of both segment ends.
 __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float y, float t, float px, float py)
@@ -220,19 +306,31 @@ __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float
     return n;
 }
 
-// stats[]: 0 samples tested, 1 samples up to and including the first colliding
-// one (what a serial scan tests), 2 list entries behind (1), 3 successors that
-// received a verdict, 4 list entries behind (3), 5 successors emitted, 6 nodes,
-// 7 shots evaluated.
+// One workgroup of five waves per popped node.
+//  phase 1: waves 0-3 evaluate the 44 Reeds-Shepp candidates of the shot to the
+//           goal, grouped so that a wave runs two of the eight closed forms;
+//           wave 4 generates the motion-primitive successors with verdict, g, h
+//           and index (src/hybrid_a_star.cpp:540-811, :316-366), pose test and
+//           swept-segment test of a successor on separate lanes;
+//  phase 2: wave 0 reduces the candidates in reference order and builds the
+//           per-segment prefix of the winning curve;
+//  phase 3: all waves sample the curve (:429-468), 320 samples a round, until a
+//           sample collides.
+// stats[] (instrumented build only): 0 samples tested, 1 samples up to and
+// including the first colliding one (what a serial scan tests), 2 list entries
+// behind (1), 3 successors that received a verdict, 4 list entries behind (3),
+// 5 successors emitted, 6 nodes, 7 shots, 8.. shader-clock sums per phase.
 template <bool STATS>
-__global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
+__global__ void __launch_bounds__(STEP_THREADS, STEP_MIN_WAVES) k_step_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
                                                           const hyas_goal *__restrict__ goals,
-                                                          const float *__restrict__ twod, // [query][w*h] or null
+                                                          const float *__restrict__ twod, // [query][twod_size] or null
                                                           const double *__restrict__ seg_tab, uint32_t seg_cap,
-                                                          uint8_t *__restrict__ shot_ok,
-                                                          float *__restrict__ shot_len, uint8_t *__restrict__ count,
-                                                          hyas_succ *__restrict__ succ, unsigned long long *stats)
+                                                          uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
+                                                          uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
+                                                          unsigned long long *stats)
 {
+    __shared__ CandOut s_cand[RS_NUM_CANDIDATES];
+    __shared__ Quad s_quads[STEP_LDS_QUADS];
     __shared__ rs::Path s_path;
     __shared__ rs::Prefix s_prefix;
     __shared__ float s_xy[STEP_THREADS][2];
@@ -249,57 +347,81 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         c0 = clock64();
     const hyas_goal goal = goals[node.query];
     const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
+    const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
+    // obstacle quads: workgroup-local copy when they fit (16 dwords each)
+    const bool quads_local = m.n_quads <= STEP_LDS_QUADS;
+    if (quads_local)
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(m.quads);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_quads);
+        for (uint32_t i = tid; i < m.n_quads * 16u; i += STEP_THREADS)
+            dst[i] = src[i];
+        __syncthreads();
+    }
+    const StepQuads sq{quads_local ? s_quads : nullptr, m.quads};
 
-    if (wave == 0)
+    // ---- phase 1 ------------------------------------------------------------
+    if (wave < 4)
     {
         if (do_shot)
         {
-            const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
-            const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
-            double x, y, phi;
-            rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
-            rs::Path p = solve_wave(x, y, phi, lane);
-            if (lane == 0)
+            // candidate groups per wave: {0,1} {2,3,10} {4,5} {6,8,7,9}: at most two
+            // distinct closed forms (plus the short CCSCC one) per wave
+            const int groups[4][4] = {{0, 1, -1, -1}, {2, 3, 10, -1}, {4, 5, -1, -1}, {6, 8, 7, 9}};
+            const int g = (lane < 16) ? groups[wave][lane >> 2] : -1;
+            if (g >= 0)
             {
-                s_path = p;
-                rs::Prefix pf;
-                rs::build_prefix(p, q0[2], pf);
-                s_prefix = pf;
+                const int c = g * 4 + (lane & 3);
+                const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
+                double x, y, phi;
+                rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
+                CandOut o;
+                o.L = 0;
+                o.valid = rs::candidate(c, x, y, phi, o.p, o.L) ? 1 : 0;
+                s_cand[c] = o;
             }
         }
-        if (lane == 0)
+        if (tid == 0)
             s_hit = 0;
     }
-    else if (wave == 1)
+    else
     {
+        // lanes 0..K-1: pose test; lanes 8..8+K-1: swept segment, g, h, index
         const int K = m.n_succ;
-        bool ok = false, evaluated = false;
+        const int which = lane & 7;
+        const bool pose_lane = lane < 8, seg_lane = lane >= 8 && lane < 16;
+        bool part_ok = false, evaluated = false;
         hyas_succ s;
-        if (lane < K)
+        float sx = 0, sy = 0, st = 0;
+        int prim = 0;
+        if ((pose_lane || seg_lane) && which < K)
         {
             float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
-            float sx, sy, st;
-            int prim;
-            if (successor_pose(m, node.x, node.y, node.t, dist, lane, sx, sy, st, prim))
+            if (successor_pose(m, node.x, node.y, node.t, dist, which, sx, sy, st, prim))
             {
                 evaluated = true;
-                ok = traversable(m, sx, sy, st, true, node.x, node.y);
-                if (ok)
-                {
-                    float step = normf(sub(f2(sx, sy), f2(node.x, node.y)));
-                    s.x = sx, s.y = sy, s.t = st;
-                    s.g = cost_so_far(m, node.g, step, prim, node.prim);
-                    s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
-                    s.idx = idx_3d(m, sx, sy, st);
-                    s.prim = (int8_t)prim;
-                    s.free = 1;
-                    s.pad = 0;
-                }
+                if (pose_lane)
+                    part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st);
+                else
+                    part_ok = segment_free(m, sq, sx, sy, node.x, node.y);
             }
         }
+        const bool pose_ok = __shfl((int)part_ok, lane & 7, 64) != 0; // verdict of the pose lane
+        const bool ok = seg_lane && evaluated && part_ok && pose_ok;
+        if (ok)
+        {
+            float step = normf(sub(f2(sx, sy), f2(node.x, node.y)));
+            s.x = sx, s.y = sy, s.t = st;
+            s.g = cost_so_far(m, node.g, step, prim, node.prim);
+            s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
+            s.idx = idx_3d(m, sx, sy, st);
+            s.prim = (int8_t)prim;
+            s.free = 1;
+            s.pad = 0;
+        }
         // compact in motion-set order, as the reference's output vector
-        unsigned long long mask = __ballot(ok);
-        unsigned long long emask = __ballot(evaluated);
+        const unsigned long long mask = __ballot(ok);
+        const unsigned long long emask = __ballot(seg_lane && evaluated);
         if (ok)
         {
             int pos = __popcll(mask & ((1ull << lane) - 1ull));
@@ -309,15 +431,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
             count[slot] = (uint8_t)(__popcll(mask) | (__popcll(emask) << 4));
         if (STATS)
         {
-            uint32_t walked = 0;
-            if (evaluated)
-            {
-                float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
-                float sx, sy, st;
-                int prim;
-                successor_pose(m, node.x, node.y, node.t, dist, lane, sx, sy, st, prim);
-                walked = lists_walked(m, sx, sy, st, node.x, node.y);
-            }
+            uint32_t walked = (seg_lane && evaluated) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
             for (int off = 32; off > 0; off >>= 1)
                 walked += __shfl_xor(walked, off, 64);
             if (lane == 0)
@@ -337,21 +451,50 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
             shot_ok[slot] = 0, shot_len[slot] = 0;
         return;
     }
+    if (STATS)
+    {
+        long long cw = clock64();
+        if (lane == 0 && wave < 5)
+            atomicAdd(&stats[11 + wave], (unsigned long long)(cw - c0)); // per-wave phase-1 time
+    }
+    __syncthreads();
+
+    // ---- phase 2 ------------------------------------------------------------
+    if (wave == 0)
+    {
+        rs::Path mine = rs::empty_path();
+        double L = 0;
+        bool valid = false;
+        if (lane < RS_NUM_CANDIDATES)
+        {
+            const CandOut &o = s_cand[lane];
+            valid = o.valid != 0;
+            mine = o.p;
+            L = o.L;
+        }
+        rs::Path best = reduce_candidates(mine, L, valid, lane);
+        rs::Prefix pf;
+        build_prefix_wave(best, q0[2], lane, pf);
+        if (lane == 0)
+        {
+            s_path = best;
+            s_prefix = pf;
+        }
+    }
     __syncthreads();
     if (STATS)
     {
         c1 = clock64();
         if (tid == 0)
-            atomicAdd(&stats[8], (unsigned long long)(c1 - c0)); // solve + successors
-        if (tid == 64)
-            atomicAdd(&stats[12], (unsigned long long)(c1 - c0));
+            atomicAdd(&stats[8], (unsigned long long)(c1 - c0)); // phases 1 + 2
     }
 
+    // ---- phase 3 ------------------------------------------------------------
     const rs::Path path = s_path;
+    const rs::Prefix pfx = s_prefix; // registers: the sampling routine is out of line
     const double rho = (double)m.shot_rho;
-    const double length = rho * path.total; // :564
+    const double length = rho * path.total; // src/ReedsShepp.cpp:564
     const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
-    const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
     float prev_x = node.x, prev_y = node.y; // predecessor of sample 0 is the node itself
     bool collided = false;
     unsigned long long tested = 0;
@@ -364,7 +507,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         if (k < nsamp)
         {
             double s[3];
-            rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
+            rs::interpolate_prefix(q0, path, pfx, seg_tab[k] / rho, rho, s);
             x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
         }
         s_xy[tid][0] = x, s_xy[tid][1] = y;
@@ -373,13 +516,13 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
         {
             c2 = clock64();
             if (tid == 0)
-                atomicAdd(&stats[9], (unsigned long long)(c2 - c1)), atomicAdd(&stats[11], 1ull); // interpolation, rounds
+                atomicAdd(&stats[9], (unsigned long long)(c2 - c1)); // interpolation
         }
         bool hit = false;
         const float px = tid ? s_xy[tid - 1][0] : prev_x, py = tid ? s_xy[tid - 1][1] : prev_y;
         if (k < nsamp)
         {
-            hit = !traversable(m, x, y, t, true, px, py);
+            hit = !traversable(m, sq, x, y, t, true, px, py);
             ++tested;
         }
         prev_x = s_xy[STEP_THREADS - 1][0], prev_y = s_xy[STEP_THREADS - 1][1];
@@ -393,9 +536,6 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
             c1 = clock64();
             if (tid == 0)
                 atomicAdd(&stats[10], (unsigned long long)(c1 - c2)); // collision tests of the round
-        }
-        if (STATS)
-        {
             const uint32_t first = s_first;
             if (k < nsamp && k <= first)
                 atomicAdd(&s_lists, lists_walked(m, x, y, t, px, py));
@@ -405,6 +545,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
                 const uint32_t last = (first == 0xFFFFFFFFu) ? ((nsamp - base < STEP_THREADS) ? nsamp - base : STEP_THREADS) : first - base + 1;
                 atomicAdd(&stats[1], (unsigned long long)last);
                 atomicAdd(&stats[2], (unsigned long long)s_lists);
+                atomicAdd(&stats[16], 1ull); // rounds
             }
         }
         if (s_hit)
@@ -415,7 +556,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step_rs(DevMap m, const StepIn
     }
     if (tid == 0)
     {
-        // an empty sample list is "no shot" (path_vec.size() == 0, :524)
+        // an empty sample list is "no shot" (path_vec.size() == 0, src/hybrid_a_star.cpp:524)
         shot_ok[slot] = (!collided && nsamp > 0) ? 1 : 0;
         shot_len[slot] = (float)length;
     }
