@@ -151,11 +151,11 @@ def main():
     roofline = None
     cpu = None
     if rank == 0:
-        ctx.set_stats(True)
+        ctx.set_stats(1)
         ctx.plan_batch(starts, goals)
         st = ctx.stats()
         _, launches_1 = ctx.kernel_ms(0)
-        ctx.set_stats(False)
+        ctx.set_stats(0)
         bytes_per_launch = algorithmic_bytes(st) / max(launches_1, 1)
         avg_ms = kern_ms / max(kern_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

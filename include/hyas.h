@@ -222,8 +222,9 @@ double hyas_last_kernel_ms(const hyas_ctx *ctx, int which, int64_t *launches);
 void hyas_reset_kernel_timers(hyas_ctx *ctx);
 
 /* Work counters of the expansion-step kernel, for roofline accounting (no
- * counterpart in the reference).  hyas_set_stats(ctx, 1) zeroes them and makes
- * hyas_plan_batch run the instrumented (slower) kernel; hyas_get_stats reads:
+ * counterpart in the reference).  hyas_set_stats(ctx, mode) zeroes them; mode 1
+ * makes hyas_plan_batch run the counting (slower) kernel, mode 2 the kernel
+ * with phase clocks only, 0 the plain one; hyas_get_stats reads:
  * 0 curve samples tested, 1 samples a serial scan would test (up to and
  * including the first colliding one), 2 obstacle-list entries behind (1),
  * 3 successors that received a verdict, 4 obstacle-list entries behind (3),

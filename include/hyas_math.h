@@ -28,7 +28,11 @@
 #define HY_HD __host__ __device__ inline
 /* the larger routines are real calls on the device: inlining every sin/cos/
  * atan2 into a kernel multiplies its code size past the instruction cache */
+#ifdef HYAS_INLINE_MATH
+#define HY_HD_CALL HY_HD
+#else
 #define HY_HD_CALL __host__ __device__ inline __attribute__((noinline))
+#endif
 #else
 #define HY_HD inline
 #define HY_HD_CALL inline

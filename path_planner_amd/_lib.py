@@ -72,7 +72,9 @@ _lib = None
 
 
 def lib_path():
-    return _HERE / "libhyas.so"
+    import os
+
+    return Path(os.environ.get("HYAS_LIB") or (_HERE / "libhyas.so"))
 
 
 def load_library():
@@ -311,13 +313,14 @@ class Hyas:
     def reset_kernel_timers(self):
         self.L.hyas_reset_kernel_timers(self.h)
 
-    def set_stats(self, enable):
-        self._check(self.L.hyas_set_stats(self.h, int(bool(enable))), "hyas_set_stats")
+    def set_stats(self, mode):
+        """0 off, 1 work counters, 2 phase clocks."""
+        self._check(self.L.hyas_set_stats(self.h, int(mode)), "hyas_set_stats")
 
     def stats(self):
         out = np.zeros(24, np.uint64)
         self._check(self.L.hyas_get_stats(self.h, _vp(out)), "hyas_get_stats")
         names = ["samples_tested", "samples_serial", "sample_list_entries", "succ_evaluated", "succ_list_entries",
                  "succ_emitted", "nodes", "shots", "clk_solve", "clk_interp", "clk_collide", "clk_w0", "clk_w1",
-                 "clk_w2", "clk_w3", "clk_w4", "rounds"]
+                 "clk_w2", "clk_w3", "clk_w4", "clk_w5", "clk_w6", "clk_w7", "rounds"]
         return dict(zip(names, (int(v) for v in out)))

@@ -13,6 +13,10 @@ struct hyas_ctx
     hyas_params P{};
     int device = 0;
     hipStream_t stream = nullptr;
+    // search rounds: two query groups in flight, each with a stream for the shot kernel and one for the
+    // successor kernel; round_stream[0][0] is `stream`
+    hipStream_t round_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t round_ev[2][5] = {}; // per group: shot begin/end, expand begin/end, input uploaded
     std::string err;
     bool have_map = false, have_table = false, grid_only = false;
 
@@ -61,6 +65,7 @@ struct hyas_ctx
     int64_t k_launches[5] = {0, 0, 0, 0, 0};
     unsigned long long *d_stats = nullptr; // 8 work counters of the step kernel
     bool stats_on = false;
+    int stats_mode = 0; // 1 work counters, 2 phase clocks
 
     int fail(int code, const std::string &msg)
     {

@@ -465,7 +465,17 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     hyas_ctx *c = new hyas_ctx();
     c->P = *params;
     c->device = device;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    c->round_stream[0][0] = c->stream;
+    for (int g = 0; g < 2 && ok; ++g)
+    {
+        for (int k = 0; k < 2 && ok; ++k)
+            if (g + k > 0)
+                ok = hipStreamCreate(&c->round_stream[g][k]) == hipSuccess;
+        for (int k = 0; k < 5 && ok; ++k)
+            ok = (k < 4 ? hipEventCreate(&c->round_ev[g][k]) : hipEventCreateWithFlags(&c->round_ev[g][k], hipEventDisableTiming)) == hipSuccess;
+    }
+    if (!ok || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->d_stats, 24 * sizeof(unsigned long long)) != hipSuccess)
     {
         fprintf(stderr, "hyas_create: stream/event creation failed\n");
@@ -495,6 +505,15 @@ void hyas_destroy(hyas_ctx *c)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
         (void)hipEventDestroy(c->ev1);
+    for (int g = 0; g < 2; ++g)
+    {
+        for (int k = 0; k < 5; ++k)
+            if (c->round_ev[g][k])
+                (void)hipEventDestroy(c->round_ev[g][k]);
+        for (int k = 0; k < 2; ++k)
+            if (g + k > 0 && c->round_stream[g][k])
+                (void)hipStreamDestroy(c->round_stream[g][k]);
+    }
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -854,8 +873,8 @@ int hyas_flood(hyas_ctx *c, const hyas_goal *goal, float *out)
     return HYAS_OK;
 }
 
-// Shared body of hyas_expand_batch / hyas_shot_batch: one step-kernel launch
-// over n independent (node, goal) pairs.
+// Shared body of hyas_expand_batch / hyas_shot_batch: one kernel launch over
+// n independent (node, goal) pairs.
 static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals, const float *twod, size_t n, int shoot, uint8_t *ok,
                     float *len, hyas_succ *succ, uint8_t *count)
 {
@@ -888,9 +907,12 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
         HYAS_HIP(c, hipMemcpyAsync(c->d_twod, twod, n * c->twod_size * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HYAS_HIP(c, hipMemsetAsync(ds + o_succ, 0, off - o_succ, c->stream));
     timer_begin(c);
-    launch_step_rs(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), twod ? c->d_twod : nullptr, c->d_seg,
-                   c->seg_cap, (uint8_t *)(ds + o_ok), (float *)(ds + o_len), (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), nullptr,
-                   c->stream);
+    if (shoot)
+        launch_shot_rs(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), c->d_seg, c->seg_cap,
+                       (uint8_t *)(ds + o_ok), (float *)(ds + o_len), nullptr, 0, c->stream);
+    else
+        launch_expand(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), twod ? c->d_twod : nullptr,
+                      (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), nullptr, 0, c->stream);
     HYAS_HIP(c, hipGetLastError());
     HYAS_HIP(c, hipStreamSynchronize(c->stream));
     timer_end(c, shoot ? 0 : 1);
@@ -972,6 +994,7 @@ int hyas_set_stats(hyas_ctx *c, int enable)
     if (!c)
         return HYAS_EINVAL;
     c->stats_on = enable != 0;
+    c->stats_mode = enable;
     HYAS_HIP(c, hipSetDevice(c->device));
     HYAS_HIP(c, hipMemset(c->d_stats, 0, 24 * sizeof(unsigned long long)));
     return HYAS_OK;

@@ -14,7 +14,11 @@
 
 #define HD __host__ __device__ __forceinline__
 // out-of-line on the device: shared by every call site instead of being copied into each
+#ifdef HYAS_INLINE_GEOM
+#define HDC HD
+#else
 #define HDC __host__ __device__ inline __attribute__((noinline))
+#endif
 
 namespace hyas
 {

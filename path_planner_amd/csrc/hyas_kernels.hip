@@ -197,7 +197,6 @@ __device__ __forceinline__ uint32_t count_samples(const double *__restrict__ seg
     return lo;
 }
 
-#define STEP_THREADS 320 // five waves
 #define STEP_LDS_QUADS 192 // obstacle quads kept in LDS (12 KB)
 
 // Quads from the workgroup's LDS copy when there is one, else from global memory.
@@ -306,155 +305,170 @@ __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float
     return n;
 }
 
-// One workgroup of five waves per popped node.
-//  phase 1: waves 0-3 evaluate the 44 Reeds-Shepp candidates of the shot to the
-//           goal, grouped so that a wave runs two of the eight closed forms;
-//           wave 4 generates the motion-primitive successors with verdict, g, h
-//           and index (src/hybrid_a_star.cpp:540-811, :316-366), pose test and
-//           swept-segment test of a successor on separate lanes;
-//  phase 2: wave 0 reduces the candidates in reference order and builds the
-//           per-segment prefix of the winning curve;
-//  phase 3: all waves sample the curve (:429-468), 320 samples a round, until a
-//           sample collides.
-// stats[] (instrumented build only): 0 samples tested, 1 samples up to and
-// including the first colliding one (what a serial scan tests), 2 list entries
-// behind (1), 3 successors that received a verdict, 4 list entries behind (3),
-// 5 successors emitted, 6 nodes, 7 shots, 8.. shader-clock sums per phase.
-template <bool STATS>
-__global__ void __launch_bounds__(STEP_THREADS, STEP_MIN_WAVES) k_step_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
-                                                          const hyas_goal *__restrict__ goals,
-                                                          const float *__restrict__ twod, // [query][twod_size] or null
-                                                          const double *__restrict__ seg_tab, uint32_t seg_cap,
-                                                          uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
-                                                          uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
-                                                          unsigned long long *stats)
+// Motion-primitive successors of n popped nodes with verdict, g, h and index
+// (src/hybrid_a_star.cpp:540-811, :316-366).  Sixteen nodes per workgroup; for
+// each node eight lanes of waves 0-1 run the pose tests of its primitives and
+// eight lanes of waves 2-3 the swept-segment tests and, for survivors, cost
+// and heuristic.
+// MODE 0: plain; 1: work counters (stats[3..6]).
+#define ROUND_THREADS 256
+#define EXPAND_THREADS ROUND_THREADS
+#define SHOT_THREADS ROUND_THREADS
+
+// workgroup-local copy of the obstacle quads when they fit (16 dwords each); the caller synchronises
+__device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads, int tid)
 {
-    __shared__ CandOut s_cand[RS_NUM_CANDIDATES];
-    __shared__ Quad s_quads[STEP_LDS_QUADS];
-    __shared__ rs::Path s_path;
-    __shared__ rs::Prefix s_prefix;
-    __shared__ float s_xy[STEP_THREADS][2];
-    __shared__ int s_hit;
-    __shared__ unsigned int s_first, s_lists;
-    const uint32_t slot = blockIdx.x;
-    if (slot >= n)
-        return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const StepIn node = in[slot];
-    const bool do_shot = node.shoot != 0; // uniform across the workgroup
-    long long c0 = 0, c1 = 0, c2 = 0;
-    if (STATS)
-        c0 = clock64();
-    const hyas_goal goal = goals[node.query];
-    const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
-    const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
-    // obstacle quads: workgroup-local copy when they fit (16 dwords each)
     const bool quads_local = m.n_quads <= STEP_LDS_QUADS;
     if (quads_local)
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(m.quads);
         uint32_t *dst = reinterpret_cast<uint32_t *>(s_quads);
-        for (uint32_t i = tid; i < m.n_quads * 16u; i += STEP_THREADS)
+        for (uint32_t i = tid; i < m.n_quads * 16u; i += ROUND_THREADS)
             dst[i] = src[i];
-        __syncthreads();
     }
-    const StepQuads sq{quads_local ? s_quads : nullptr, m.quads};
+    return StepQuads{quads_local ? s_quads : nullptr, m.quads};
+}
 
-    // ---- phase 1 ------------------------------------------------------------
-    if (wave < 4)
+template <int MODE>
+__device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__restrict__ in, uint32_t n, const hyas_goal *__restrict__ goals,
+                                            const float *__restrict__ twod, uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
+                                            unsigned long long *stats, Quad *s_quads, uint32_t block)
+{
+    const int tid = threadIdx.x;
+    const StepQuads sq = stage_quads(m, s_quads, tid);
+    __syncthreads();
+    __shared__ uint8_t s_pose[EXPAND_THREADS / 2];
+    // eight lanes per node and test; waves 0-1 run the pose tests, waves 2-3 the swept-segment tests
+    // (a wave that mixed the two would run them one after the other)
+    const int lane = tid & 63, sl = tid & 7, local = (tid & 127) >> 3;
+    const uint32_t slot = block * (EXPAND_THREADS / 16) + local;
+    const bool live = slot < n;
+    const StepIn node = in[live ? slot : 0];
+    const hyas_goal goal = goals[node.query];
+    const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
+    const int K = m.n_succ;
+    const bool pose_lane = tid < EXPAND_THREADS / 2, seg_lane = !pose_lane;
+    bool part_ok = false, evaluated = false;
+    float sx = 0, sy = 0, st = 0;
+    int prim = 0;
+    if (live && sl < K)
     {
-        if (do_shot)
+        float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
+        if (successor_pose(m, node.x, node.y, node.t, dist, sl, sx, sy, st, prim))
         {
-            // candidate groups per wave: {0,1} {2,3,10} {4,5} {6,8,7,9}: at most two
-            // distinct closed forms (plus the short CCSCC one) per wave
-            const int groups[4][4] = {{0, 1, -1, -1}, {2, 3, 10, -1}, {4, 5, -1, -1}, {6, 8, 7, 9}};
-            const int g = (lane < 16) ? groups[wave][lane >> 2] : -1;
-            if (g >= 0)
-            {
-                const int c = g * 4 + (lane & 3);
-                const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
-                double x, y, phi;
-                rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
-                CandOut o;
-                o.L = 0;
-                o.valid = rs::candidate(c, x, y, phi, o.p, o.L) ? 1 : 0;
-                s_cand[c] = o;
-            }
-        }
-        if (tid == 0)
-            s_hit = 0;
-    }
-    else
-    {
-        // lanes 0..K-1: pose test; lanes 8..8+K-1: swept segment, g, h, index
-        const int K = m.n_succ;
-        const int which = lane & 7;
-        const bool pose_lane = lane < 8, seg_lane = lane >= 8 && lane < 16;
-        bool part_ok = false, evaluated = false;
-        hyas_succ s;
-        float sx = 0, sy = 0, st = 0;
-        int prim = 0;
-        if ((pose_lane || seg_lane) && which < K)
-        {
-            float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
-            if (successor_pose(m, node.x, node.y, node.t, dist, which, sx, sy, st, prim))
-            {
-                evaluated = true;
-                if (pose_lane)
-                    part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st);
-                else
-                    part_ok = segment_free(m, sq, sx, sy, node.x, node.y);
-            }
-        }
-        const bool pose_ok = __shfl((int)part_ok, lane & 7, 64) != 0; // verdict of the pose lane
-        const bool ok = seg_lane && evaluated && part_ok && pose_ok;
-        if (ok)
-        {
-            float step = normf(sub(f2(sx, sy), f2(node.x, node.y)));
-            s.x = sx, s.y = sy, s.t = st;
-            s.g = cost_so_far(m, node.g, step, prim, node.prim);
-            s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
-            s.idx = idx_3d(m, sx, sy, st);
-            s.prim = (int8_t)prim;
-            s.free = 1;
-            s.pad = 0;
-        }
-        // compact in motion-set order, as the reference's output vector
-        const unsigned long long mask = __ballot(ok);
-        const unsigned long long emask = __ballot(seg_lane && evaluated);
-        if (ok)
-        {
-            int pos = __popcll(mask & ((1ull << lane) - 1ull));
-            succ[(size_t)slot * m.n_succ + pos] = s;
-        }
-        if (lane == 0) // low nibble: emitted successors, high nibble: candidates that got a verdict
-            count[slot] = (uint8_t)(__popcll(mask) | (__popcll(emask) << 4));
-        if (STATS)
-        {
-            uint32_t walked = (seg_lane && evaluated) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
-            for (int off = 32; off > 0; off >>= 1)
-                walked += __shfl_xor(walked, off, 64);
-            if (lane == 0)
-            {
-                atomicAdd(&stats[3], (unsigned long long)__popcll(emask));
-                atomicAdd(&stats[4], (unsigned long long)walked);
-                atomicAdd(&stats[5], (unsigned long long)__popcll(mask));
-                atomicAdd(&stats[6], 1ull);
-                if (do_shot)
-                    atomicAdd(&stats[7], 1ull);
-            }
+            evaluated = true;
+            if (pose_lane)
+                part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st);
+            else
+                part_ok = segment_free(m, sq, sx, sy, node.x, node.y);
         }
     }
-    if (!do_shot)
+    if (pose_lane)
+        s_pose[tid] = part_ok ? 1 : 0;
+    __syncthreads();
+    const bool ok = seg_lane && evaluated && part_ok && s_pose[tid & 127] != 0;
+    hyas_succ s;
+    if (ok)
+    {
+        float step = normf(sub(f2(sx, sy), f2(node.x, node.y)));
+        s.x = sx, s.y = sy, s.t = st;
+        s.g = cost_so_far(m, node.g, step, prim, node.prim);
+        s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
+        s.idx = idx_3d(m, sx, sy, st);
+        s.prim = (int8_t)prim;
+        s.free = 1;
+        s.pad = 0;
+    }
+    // compact in motion-set order, as the reference's output vector
+    const unsigned grp = (lane >> 3) * 8;
+    const unsigned mask = (unsigned)((__ballot(ok) >> grp) & 0xFFull);
+    const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & 0xFFull);
+    if (ok)
+    {
+        int pos = __popc(mask & ((1u << sl) - 1u));
+        succ[(size_t)slot * m.n_succ + pos] = s;
+    }
+    const bool writer = live && seg_lane && sl == 0;
+    if (writer) // low nibble: emitted successors, high nibble: candidates that got a verdict
+        count[slot] = (uint8_t)(__popc(mask) | (__popc(emask) << 4));
+    if (MODE == 1)
+    {
+        uint32_t walked = (seg_lane && evaluated) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
+        for (int off = 4; off > 0; off >>= 1)
+            walked += __shfl_xor(walked, off, 64);
+        if (writer)
+        {
+            atomicAdd(&stats[3], (unsigned long long)__popc(emask));
+            atomicAdd(&stats[4], (unsigned long long)walked);
+            atomicAdd(&stats[5], (unsigned long long)__popc(mask));
+            atomicAdd(&stats[6], 1ull);
+        }
+    }
+}
+
+// Analytic Reeds-Shepp shot of one popped node (src/hybrid_a_star.cpp:429-468),
+// one workgroup of four waves per node.
+//  phase 1: the 44 closed-form candidates, grouped so that a wave runs two or
+//           three of the eight closed forms;
+//  phase 2: wave 0 reduces the candidates in reference order and builds the
+//           per-segment prefix of the winning curve;
+//  phase 3: all lanes interpolate 256 samples of the curve at a time; the
+//           samples are then tested 128 at a time, pose tests on waves 0-1 and
+//           swept-segment tests on waves 2-3, until one collides.
+// stats[] (MODE 1): 0 samples tested, 1 samples up to and including the first
+// colliding one (what a serial scan tests), 2 obstacle-list entries behind (1),
+// 7 shots; (MODE 2) shader-clock sums: 8 phases 1+2, 9 interpolation,
+// 10 collision tests, 11..14 phase 1 per wave, 6 workgroups, 19 sample batches.
+template <int MODE>
+__device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restrict__ in, const hyas_goal *__restrict__ goals,
+                                          const double *__restrict__ seg_tab, uint32_t seg_cap, uint8_t *__restrict__ shot_ok,
+                                          float *__restrict__ shot_len, unsigned long long *stats, Quad *s_quads, uint32_t slot)
+{
+    __shared__ CandOut s_cand[RS_NUM_CANDIDATES];
+    __shared__ rs::Path s_path;
+    __shared__ rs::Prefix s_prefix;
+    __shared__ float s_xyt[SHOT_THREADS + 1][3]; // [0] = the sample in front of this batch
+    __shared__ int s_hit;
+    __shared__ unsigned int s_first, s_lists;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const StepIn node = in[slot];
+    if (node.shoot == 0) // uniform across the workgroup
     {
         if (tid == 0)
             shot_ok[slot] = 0, shot_len[slot] = 0;
         return;
     }
-    if (STATS)
+    constexpr bool STATS = MODE == 1, CLOCKS = MODE == 2;
+    long long c0 = 0, c1 = 0, c2 = 0;
+    if (CLOCKS)
+        c0 = clock64();
+    const hyas_goal goal = goals[node.query];
+    const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
+    const StepQuads sq = stage_quads(m, s_quads, tid); // visible after the barrier that ends phase 1
+
+    // ---- phase 1 ------------------------------------------------------------
+    {
+        // candidate groups per wave (group = closed form x backwards?, four symmetries each)
+        const int groups[4][3] = {{0, 1, 10}, {2, 3, 9}, {4, 5, -1}, {6, 8, 7}};
+        const int g = (lane < 12) ? groups[wave][lane >> 2] : -1;
+        if (g >= 0)
+        {
+            const int c = g * 4 + (lane & 3);
+            const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
+            double x, y, phi;
+            rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
+            CandOut o;
+            o.L = 0;
+            o.valid = rs::candidate(c, x, y, phi, o.p, o.L) ? 1 : 0;
+            s_cand[c] = o;
+        }
+        if (tid == 0)
+            s_hit = 0;
+    }
+    if (CLOCKS)
     {
         long long cw = clock64();
-        if (lane == 0 && wave < 5)
+        if (lane == 0)
             atomicAdd(&stats[11 + wave], (unsigned long long)(cw - c0)); // per-wave phase-1 time
     }
     __syncthreads();
@@ -479,79 +493,106 @@ __global__ void __launch_bounds__(STEP_THREADS, STEP_MIN_WAVES) k_step_rs(DevMap
         {
             s_path = best;
             s_prefix = pf;
+            s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t; // predecessor of sample 0: the node
         }
     }
     __syncthreads();
-    if (STATS)
+    if (CLOCKS)
     {
         c1 = clock64();
         if (tid == 0)
-            atomicAdd(&stats[8], (unsigned long long)(c1 - c0)); // phases 1 + 2
+            atomicAdd(&stats[8], (unsigned long long)(c1 - c0)), atomicAdd(&stats[6], 1ull);
     }
 
     // ---- phase 3 ------------------------------------------------------------
     const rs::Path path = s_path;
-    const rs::Prefix pfx = s_prefix; // registers: the sampling routine is out of line
     const double rho = (double)m.shot_rho;
     const double length = rho * path.total; // src/ReedsShepp.cpp:564
     const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
-    float prev_x = node.x, prev_y = node.y; // predecessor of sample 0 is the node itself
     bool collided = false;
     unsigned long long tested = 0;
-    for (uint32_t base = 0; base < nsamp; base += STEP_THREADS)
+    for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_THREADS)
     {
-        if (STATS && tid == 0)
-            s_first = 0xFFFFFFFFu, s_lists = 0;
-        const uint32_t k = base + tid;
-        float x = 0, y = 0, t = 0;
-        if (k < nsamp)
+        if (base)
         {
-            double s[3];
-            rs::interpolate_prefix(q0, path, pfx, seg_tab[k] / rho, rho, s);
-            x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+            __syncthreads(); // everyone is done with the previous batch
+            if (tid == 0)
+                s_xyt[0][0] = s_xyt[SHOT_THREADS][0], s_xyt[0][1] = s_xyt[SHOT_THREADS][1];
         }
-        s_xy[tid][0] = x, s_xy[tid][1] = y;
+        {
+            const uint32_t k = base + tid;
+            float x = 0, y = 0, t = 0;
+            if (k < nsamp)
+            {
+                double s[3];
+                rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
+                x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+            }
+            if (base)
+                __syncthreads(); // slot 0 has been refreshed before slot SHOT_THREADS is overwritten
+            s_xyt[tid + 1][0] = x, s_xyt[tid + 1][1] = y, s_xyt[tid + 1][2] = t;
+        }
         __syncthreads();
-        if (STATS)
+        if (CLOCKS)
         {
             c2 = clock64();
             if (tid == 0)
-                atomicAdd(&stats[9], (unsigned long long)(c2 - c1)); // interpolation
+                atomicAdd(&stats[9], (unsigned long long)(c2 - c1)), atomicAdd(&stats[19], 1ull);
         }
-        bool hit = false;
-        const float px = tid ? s_xy[tid - 1][0] : prev_x, py = tid ? s_xy[tid - 1][1] : prev_y;
-        if (k < nsamp)
+        // two test rounds: the first half of the workgroup runs the pose tests, the second half the swept-segment tests
+        for (int half = 0; half < 2; ++half)
         {
-            hit = !traversable(m, sq, x, y, t, true, px, py);
-            ++tested;
+            const uint32_t j = half * (SHOT_THREADS / 2) + (tid & (SHOT_THREADS / 2 - 1)); // sample inside the batch
+            const uint32_t k = base + j;
+            const bool pose_lane = tid < SHOT_THREADS / 2;
+            if (base + half * (SHOT_THREADS / 2) >= nsamp)
+                break;
+            if (STATS && tid == 0)
+                s_first = 0xFFFFFFFFu, s_lists = 0;
+            if (STATS)
+                __syncthreads();
+            bool hit = false;
+            const float x = s_xyt[j + 1][0], y = s_xyt[j + 1][1], t = s_xyt[j + 1][2];
+            const float px = s_xyt[j][0], py = s_xyt[j][1];
+            if (k < nsamp)
+            {
+                if (pose_lane)
+                    hit = !(on_grid(m, x, y) && pose_free(m, sq, x, y, t));
+                else
+                    hit = !segment_free(m, sq, x, y, px, py);
+                tested += pose_lane;
+            }
+            if (hit)
+                s_hit = 1;
+            if (STATS && hit)
+                atomicMin(&s_first, k);
+            __syncthreads();
+            if (STATS)
+            {
+                const uint32_t first = s_first;
+                if (k < nsamp && k <= first && pose_lane)
+                    atomicAdd(&s_lists, lists_walked(m, x, y, t, px, py));
+                __syncthreads();
+                if (tid == 0)
+                {
+                    const uint32_t lo = base + half * (SHOT_THREADS / 2);
+                    const uint32_t in_round = (nsamp - lo < SHOT_THREADS / 2) ? nsamp - lo : SHOT_THREADS / 2;
+                    const uint32_t last = (first == 0xFFFFFFFFu) ? in_round : first - lo + 1;
+                    atomicAdd(&stats[1], (unsigned long long)last);
+                    atomicAdd(&stats[2], (unsigned long long)s_lists);
+                }
+            }
+            if (s_hit)
+            {
+                collided = true;
+                break;
+            }
         }
-        prev_x = s_xy[STEP_THREADS - 1][0], prev_y = s_xy[STEP_THREADS - 1][1];
-        if (hit)
-            s_hit = 1;
-        if (STATS && hit)
-            atomicMin(&s_first, k);
-        __syncthreads();
-        if (STATS)
+        if (CLOCKS)
         {
             c1 = clock64();
             if (tid == 0)
-                atomicAdd(&stats[10], (unsigned long long)(c1 - c2)); // collision tests of the round
-            const uint32_t first = s_first;
-            if (k < nsamp && k <= first)
-                atomicAdd(&s_lists, lists_walked(m, x, y, t, px, py));
-            __syncthreads();
-            if (tid == 0)
-            {
-                const uint32_t last = (first == 0xFFFFFFFFu) ? ((nsamp - base < STEP_THREADS) ? nsamp - base : STEP_THREADS) : first - base + 1;
-                atomicAdd(&stats[1], (unsigned long long)last);
-                atomicAdd(&stats[2], (unsigned long long)s_lists);
-                atomicAdd(&stats[16], 1ull); // rounds
-            }
-        }
-        if (s_hit)
-        {
-            collided = true;
-            break;
+                atomicAdd(&stats[10], (unsigned long long)(c1 - c2));
         }
     }
     if (tid == 0)
@@ -560,8 +601,54 @@ __global__ void __launch_bounds__(STEP_THREADS, STEP_MIN_WAVES) k_step_rs(DevMap
         shot_ok[slot] = (!collided && nsamp > 0) ? 1 : 0;
         shot_len[slot] = (float)length;
     }
-    if (STATS && tested)
-        atomicAdd(&stats[0], tested);
+    if (STATS)
+    {
+        if (tested)
+            atomicAdd(&stats[0], tested);
+        if (tid == 0)
+            atomicAdd(&stats[7], 1ull);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(ROUND_THREADS) k_expand(DevMap m, const StepIn *__restrict__ in, uint32_t n,
+                                                          const hyas_goal *__restrict__ goals,
+                                                          const float *__restrict__ twod, // [query][twod_size] or null
+                                                          uint8_t *__restrict__ count, hyas_succ *__restrict__ succ, unsigned long long *stats)
+{
+    __shared__ Quad s_quads[STEP_LDS_QUADS];
+    expand_role<MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_shot_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
+                                                                          const hyas_goal *__restrict__ goals,
+                                                                          const double *__restrict__ seg_tab, uint32_t seg_cap,
+                                                                          uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
+                                                                          unsigned long long *stats)
+{
+    __shared__ Quad s_quads[STEP_LDS_QUADS];
+    if (blockIdx.x < n)
+        shot_role<MODE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
+}
+
+// One search round in one launch: workgroups [0, n) evaluate the analytic shot
+// of node i, the following ceil(n / 16) workgroups the successors of 16 nodes
+// each.  The two parts are independent; the shot workgroups come first because
+// they run longest.
+template <int MODE>
+__global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap m, const StepIn *__restrict__ in, uint32_t n,
+                                                                        const hyas_goal *__restrict__ goals, const float *__restrict__ twod,
+                                                                        const double *__restrict__ seg_tab, uint32_t seg_cap,
+                                                                        uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
+                                                                        uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
+                                                                        unsigned long long *stats)
+{
+    __shared__ Quad s_quads[STEP_LDS_QUADS];
+    if (blockIdx.x < n) // uniform across the workgroup
+        shot_role<MODE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
+    else
+        expand_role<MODE == 2 ? 0 : MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n);
 }
 
 // Writes the accepted curve of one query: n samples {x, y, t} (+ the caller
@@ -654,18 +741,44 @@ void launch_table_lookup(const DevMap &m, const float *xyt, size_t n, float *cos
         hipLaunchKernelGGL(k_table_lookup, dim3(grid_for(n)), dim3(256), 0, s, m, xyt, n, cost);
 }
 
-void launch_step_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
-                    uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                    hipStream_t s)
+void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, uint8_t *count,
+                   hyas_succ *succ, unsigned long long *stats, int stats_mode, hipStream_t s)
 {
     if (!n)
         return;
-    if (stats)
-        hipLaunchKernelGGL(k_step_rs<true>, dim3(n), dim3(STEP_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
-                           count, succ, stats);
+    const dim3 grid((n + EXPAND_THREADS / 16 - 1) / (EXPAND_THREADS / 16));
+    if (stats && stats_mode == 1)
+        hipLaunchKernelGGL(k_expand<1>, grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
     else
-        hipLaunchKernelGGL(k_step_rs<false>, dim3(n), dim3(STEP_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
-                           count, succ, stats);
+        hipLaunchKernelGGL(k_expand<0>, grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
+}
+
+void launch_shot_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
+                    uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s)
+{
+    if (!n)
+        return;
+    if (stats && stats_mode == 2)
+        hipLaunchKernelGGL(k_shot_rs<2>, dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
+    else if (stats && stats_mode == 1)
+        hipLaunchKernelGGL(k_shot_rs<1>, dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
+    else
+        hipLaunchKernelGGL(k_shot_rs<0>, dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
+}
+
+void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
+                  uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
+                  int stats_mode, hipStream_t s)
+{
+    if (!n)
+        return;
+    const dim3 grid(n + (n + ROUND_THREADS / 16 - 1) / (ROUND_THREADS / 16));
+    if (stats && stats_mode == 2)
+        hipLaunchKernelGGL(k_round<2>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
+    else if (stats && stats_mode == 1)
+        hipLaunchKernelGGL(k_round<1>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
+    else
+        hipLaunchKernelGGL(k_round<0>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
 }
 
 void launch_shot_path(const DevMap &m, const StepIn &node, const hyas_goal &goal, const double *seg_tab, uint32_t seg_cap, float *out,

@@ -11,7 +11,11 @@
 #include "../../include/hyas_math.h"
 
 #define RS_HD __host__ __device__ __forceinline__
+#ifdef HYAS_INLINE_GEOM
+#define RS_HDC RS_HD
+#else
 #define RS_HDC __host__ __device__ inline __attribute__((noinline))
+#endif
 
 namespace hyas
 {
@@ -404,7 +408,7 @@ RS_HDC void build_prefix(const Path &path, double phi0, Prefix &P)
 }
 
 // Same result as interpolate(q0, path, seg, rho, s), bit for bit.
-RS_HDC void interpolate_prefix(const double q0[3], const Path &path, const Prefix &P, double seg, double rho, double s[3])
+RS_HD void interpolate_prefix(const double q0[3], const Path &path, const Prefix &P, double seg, double rho, double s[3])
 {
     if (seg < 0.0)
         seg = 0.0;

@@ -7,6 +7,7 @@
 // the one a one-query-at-a-time run produces.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -485,8 +486,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         // staging layout (one pinned block, one device block)
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
+        auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
         const size_t o_in = take(cn * sizeof(StepIn));
-        const size_t o_succ = take(cn * K * sizeof(hyas_succ)), o_len = take(cn * sizeof(float)), o_ok = take(cn), o_cnt = take(cn);
+        const size_t o_succ = take(2 * res_stride((cn + 1) / 2));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
         const size_t o_twod_host = take(cn * twod * sizeof(float));
         int rc = ensure_scratch(c, o_twod_host, off);
@@ -498,9 +501,6 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         StepIn *h_in = (StepIn *)(hs + o_in);
         hyas_goal *h_goal = (hyas_goal *)(hs + o_goal);
         float *h_twod = (float *)(hs + o_twod_host);
-        const hyas_succ *h_succ = (const hyas_succ *)(hs + o_succ);
-        const float *h_len = (const float *)(hs + o_len);
-        const uint8_t *h_ok = (const uint8_t *)(hs + o_ok), *h_cnt = (const uint8_t *)(hs + o_cnt);
 
         // makePlan pre-checks (src/hybrid_a_star_planner.cpp:126-155): start
         // and goal poses through the pose test on the GPU
@@ -584,59 +584,116 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         HYAS_HIP(c, hipStreamSynchronize(c->stream));
 
 
-        // rounds
-        std::vector<uint32_t> live(cn), slot_of;
-        for (size_t i = 0; i < cn; ++i)
-            live[i] = (uint32_t)i;
-        std::vector<uint8_t> wants(cn);
-        while (true)
+        // rounds.  The chunk's queries form two groups that take turns: while the
+        // kernels of one group run, the host pushes the other group's successors
+        // and pops its next nodes.
+        struct Group
         {
-            // host: pop phase
-            pool.run(live.size(), [&](size_t a, size_t b) {
+            std::vector<uint32_t> live, keep;
+            size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
+            bool inflight = false;
+        } G[2];
+        for (size_t i = 0; i < cn; ++i)
+            G[i >= (cn + 1) / 2].live.push_back((uint32_t)i);
+        G[1].s0 = (cn + 1) / 2;
+        std::vector<uint8_t> wants(cn);
+        double t_pop = 0, t_launch = 0, t_wait = 0, t_push = 0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        // pop phase of one group; false when all its queries have finished
+        auto prepare = [&](Group &g) -> bool {
+            const double t0 = now();
+            pool.run(g.live.size(), [&](size_t a, size_t b) {
                 for (size_t k = a; k < b; ++k)
                 {
-                    Query &q = Q[live[k]];
-                    wants[live[k]] = (!q.done && D.advance(q)) ? 1 : 0;
+                    Query &q = Q[g.live[k]];
+                    wants[g.live[k]] = (!q.done && D.advance(q)) ? 1 : 0;
                 }
             });
-            slot_of.clear();
-            for (uint32_t qi : live)
+            g.keep.clear();
+            for (uint32_t qi : g.live)
                 if (wants[qi])
-                    slot_of.push_back(qi);
-            live = slot_of; // queries that finished drop out
-            const size_t ns = live.size();
-            if (ns == 0)
-                break;
-            for (size_t s = 0; s < ns; ++s)
+                    g.keep.push_back(qi);
+            g.live.swap(g.keep); // queries that finished drop out
+            g.ns = g.live.size();
+            for (size_t s = 0; s < g.ns; ++s)
             {
-                const Query &q = Q[live[s]];
+                const Query &q = Q[g.live[s]];
                 const SNode &nd = q.arena[q.cur];
-                h_in[s] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, live[s], q.shoot ? 1u : 0u, 0};
+                h_in[g.s0 + s] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, g.live[s], q.shoot ? 1u : 0u, 0};
             }
-            HYAS_HIP(c, hipMemcpyAsync(ds + o_in, h_in, ns * sizeof(StepIn), hipMemcpyHostToDevice, c->stream));
-            timer_begin(c);
-            launch_step_rs(m, (const StepIn *)(ds + o_in), (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap,
-                           (uint8_t *)(ds + o_ok), (float *)(ds + o_len), (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ),
-                           c->stats_on ? c->d_stats : nullptr, c->stream);
-            (void)hipEventRecord(c->ev1, c->stream);
-            HYAS_HIP(c, hipMemcpyAsync(hs + o_succ, ds + o_succ, ns * K * sizeof(hyas_succ), hipMemcpyDeviceToHost, c->stream));
-            HYAS_HIP(c, hipMemcpyAsync(hs + o_len, ds + o_len, ns * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            HYAS_HIP(c, hipMemcpyAsync(hs + o_ok, ds + o_ok, ns, hipMemcpyDeviceToHost, c->stream));
-            HYAS_HIP(c, hipMemcpyAsync(hs + o_cnt, ds + o_cnt, ns, hipMemcpyDeviceToHost, c->stream));
-            HYAS_HIP(c, hipStreamSynchronize(c->stream));
-            {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess)
-                    c->k_ms[0] += ms;
-                c->k_launches[0] += 1;
-            }
-            // host: push phase
-            pool.run(ns, [&](size_t a, size_t b) {
+            t_pop += now() - t0;
+            return g.ns != 0;
+        };
+        // one upload, one launch and one download per round; each group owns a stream and a slice of the
+        // staging block, laid out for the group's current size so the results come back in one copy
+        auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) -> size_t {
+            const size_t cap = (cn + 1) / 2;
+            size_t o = o_succ + (&g - G) * res_stride(cap);
+            p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
+            p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
+            p_ok = o, o += (g.ns + 15) & ~(size_t)15;
+            p_cnt = o, o += (g.ns + 15) & ~(size_t)15;
+            return o - p_succ;
+        };
+        auto launch = [&](Group &g, int gi) -> int {
+            hipStream_t st = c->round_stream[gi][0];
+            hipEvent_t *ev = c->round_ev[gi];
+            const size_t s0 = g.s0, ns = g.ns;
+            const double t0 = now();
+            size_t p_succ, p_len, p_ok, p_cnt;
+            const size_t bytes = slice(g, p_succ, p_len, p_ok, p_cnt);
+            const StepIn *d_in = (const StepIn *)(ds + o_in) + s0;
+            HYAS_HIP(c, hipMemcpyAsync(ds + o_in + s0 * sizeof(StepIn), h_in + s0, ns * sizeof(StepIn), hipMemcpyHostToDevice, st));
+            (void)hipEventRecord(ev[0], st);
+            launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(ds + p_ok),
+                         (float *)(ds + p_len), (uint8_t *)(ds + p_cnt), (hyas_succ *)(ds + p_succ), c->stats_on ? c->d_stats : nullptr,
+                         c->stats_mode, st);
+            (void)hipEventRecord(ev[1], st);
+            HYAS_HIP(c, hipMemcpyAsync(hs + p_succ, ds + p_succ, bytes, hipMemcpyDeviceToHost, st));
+            g.inflight = true;
+            t_launch += now() - t0;
+            return HYAS_OK;
+        };
+        // wait for a group's kernel, then the push phase
+        auto collect = [&](Group &g, int gi) -> int {
+            const double t0 = now();
+            HYAS_HIP(c, hipStreamSynchronize(c->round_stream[gi][0]));
+            g.inflight = false;
+            const double t1 = now();
+            t_wait += t1 - t0;
+            float ms = 0;
+            hipEvent_t *ev = c->round_ev[gi];
+            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess)
+                c->k_ms[0] += ms;
+            c->k_launches[0] += 1;
+            size_t p_succ, p_len, p_ok, p_cnt;
+            (void)slice(g, p_succ, p_len, p_ok, p_cnt);
+            const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
+            const float *r_len = (const float *)(hs + p_len);
+            const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
+            pool.run(g.ns, [&](size_t a, size_t b) {
                 for (size_t s = a; s < b; ++s)
-                    D.consume(Q[live[s]], h_ok[s], h_len[s], h_cnt[s], h_succ + s * K);
+                    D.consume(Q[g.live[s]], r_ok[s], r_len[s], r_cnt[s], r_succ + s * K);
             });
-        }
+            t_push += now() - t1;
+            return HYAS_OK;
+        };
+        for (int gi = 0; gi < 2; ++gi)
+            if (prepare(G[gi]) && (rc = launch(G[gi], gi)) != HYAS_OK)
+                return rc;
+        while (G[0].inflight || G[1].inflight)
+            for (int gi = 0; gi < 2; ++gi)
+            {
+                if (!G[gi].inflight)
+                    continue;
+                if ((rc = collect(G[gi], gi)) != HYAS_OK)
+                    return rc;
+                if (prepare(G[gi]) && (rc = launch(G[gi], gi)) != HYAS_OK)
+                    return rc;
+            }
 
+        if (std::getenv("HYAS_TRACE"))
+            fprintf(stderr, "hyas rounds: pop %.3f s, launch %.3f s, wait %.3f s, push %.3f s\n", t_pop, t_launch, t_wait, t_push);
         // queries closed by an analytic shot: fetch the curve samples
         // (:160-172: TracePath + the sampled curve + the goal)
         for (size_t i = 0; i < cn; ++i)
