@@ -8,15 +8,17 @@
 
 #include "hyas_kernels.h"
 
+#define HYAS_MAX_GROUPS 8
+
 struct hyas_ctx
 {
     hyas_params P{};
     int device = 0;
     hipStream_t stream = nullptr;
-    // search rounds: two query groups in flight, each with a stream for the shot kernel and one for the
-    // successor kernel; round_stream[0][0] is `stream`
-    hipStream_t round_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    hipEvent_t round_ev[2][5] = {}; // per group: shot begin/end, expand begin/end, input uploaded
+    // search rounds: up to HYAS_MAX_GROUPS query groups in flight, one stream each (round_stream[0] is `stream`)
+    // and a begin/end event pair around the group's kernel
+    hipStream_t round_stream[HYAS_MAX_GROUPS] = {};
+    hipEvent_t round_ev[HYAS_MAX_GROUPS][2] = {};
     std::string err;
     bool have_map = false, have_table = false, grid_only = false;
 

@@ -466,14 +466,13 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     c->P = *params;
     c->device = device;
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-    c->round_stream[0][0] = c->stream;
-    for (int g = 0; g < 2 && ok; ++g)
+    c->round_stream[0] = c->stream;
+    for (int g = 0; g < HYAS_MAX_GROUPS && ok; ++g)
     {
+        if (g > 0)
+            ok = hipStreamCreate(&c->round_stream[g]) == hipSuccess;
         for (int k = 0; k < 2 && ok; ++k)
-            if (g + k > 0)
-                ok = hipStreamCreate(&c->round_stream[g][k]) == hipSuccess;
-        for (int k = 0; k < 5 && ok; ++k)
-            ok = (k < 4 ? hipEventCreate(&c->round_ev[g][k]) : hipEventCreateWithFlags(&c->round_ev[g][k], hipEventDisableTiming)) == hipSuccess;
+            ok = hipEventCreate(&c->round_ev[g][k]) == hipSuccess;
     }
     if (!ok || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->d_stats, 24 * sizeof(unsigned long long)) != hipSuccess)
@@ -505,14 +504,13 @@ void hyas_destroy(hyas_ctx *c)
         (void)hipEventDestroy(c->ev0);
     if (c->ev1)
         (void)hipEventDestroy(c->ev1);
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < HYAS_MAX_GROUPS; ++g)
     {
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < 2; ++k)
             if (c->round_ev[g][k])
                 (void)hipEventDestroy(c->round_ev[g][k]);
-        for (int k = 0; k < 2; ++k)
-            if (g + k > 0 && c->round_stream[g][k])
-                (void)hipStreamDestroy(c->round_stream[g][k]);
+        if (g > 0 && c->round_stream[g])
+            (void)hipStreamDestroy(c->round_stream[g]);
     }
     if (c->stream)
         (void)hipStreamDestroy(c->stream);

@@ -13,6 +13,8 @@
 #include <functional>
 #include <thread>
 
+#include <sched.h>
+
 #include "hyas_ctx.h"
 
 namespace hyas
@@ -451,7 +453,11 @@ int host_threads()
         if (v >= 1)
             return std::min(v, 256);
     }
+    // the CPUs this process may run on: the workers spin between rounds, so more threads than CPUs stall each other
     unsigned hc = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0)
+        hc = (unsigned)CPU_COUNT(&set);
     return (int)std::min<unsigned>(std::max<unsigned>(hc, 1), 16);
 }
 
@@ -475,6 +481,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t chunk_cap = 4096;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
+    size_t n_groups = 2; // query groups in flight at once
+    if (const char *e = std::getenv("HYAS_GROUPS"))
+        n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
     const size_t twod = c->twod_size;
     std::vector<float> shot_buf;
 
@@ -489,7 +498,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
         const size_t o_in = take(cn * sizeof(StepIn));
-        const size_t o_succ = take(2 * res_stride((cn + 1) / 2));
+        const int ng = (int)std::min<size_t>(n_groups, cn);
+        const size_t gcap = (cn + ng - 1) / ng; // queries per group
+        const size_t o_succ = take(ng * res_stride(gcap));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
         const size_t o_twod_host = take(cn * twod * sizeof(float));
         int rc = ensure_scratch(c, o_twod_host, off);
@@ -584,28 +595,49 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         HYAS_HIP(c, hipStreamSynchronize(c->stream));
 
 
-        // rounds.  The chunk's queries form two groups that take turns: while the
-        // kernels of one group run, the host pushes the other group's successors
+        // rounds.  The chunk's queries form groups that take turns: while the
+        // kernels of the other groups run, the host pushes one group's successors
         // and pops its next nodes.
         struct Group
         {
             std::vector<uint32_t> live, keep;
             size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
             bool inflight = false;
-        } G[2];
-        for (size_t i = 0; i < cn; ++i)
-            G[i >= (cn + 1) / 2].live.push_back((uint32_t)i);
-        G[1].s0 = (cn + 1) / 2;
+        } G[HYAS_MAX_GROUPS];
+        for (int gi = 0; gi < ng; ++gi)
+        {
+            G[gi].s0 = (size_t)gi * gcap;
+            for (size_t i = G[gi].s0; i < std::min(cn, G[gi].s0 + gcap); ++i)
+                G[gi].live.push_back((uint32_t)i);
+        }
         std::vector<uint8_t> wants(cn);
-        double t_pop = 0, t_launch = 0, t_wait = 0, t_push = 0;
+        double t_host = 0, t_launch = 0, t_wait = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        // pop phase of one group; false when all its queries have finished
-        auto prepare = [&](Group &g) -> bool {
+        // each group owns a stream and a slice of the staging block, laid out for the group's current size so the
+        // results of a round come back in one copy
+        auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) -> size_t {
+            size_t o = o_succ + (&g - G) * res_stride(gcap);
+            p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
+            p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
+            p_ok = o, o += (g.ns + 15) & ~(size_t)15;
+            p_cnt = o, o += (g.ns + 15) & ~(size_t)15;
+            return o - p_succ;
+        };
+        // host part of a round for one group: push the successors of the round that just finished (if any), pop
+        // the next node of every query; false when all queries of the group have finished
+        auto host_round = [&](Group &g, bool have_results) -> bool {
             const double t0 = now();
+            size_t p_succ, p_len, p_ok, p_cnt;
+            (void)slice(g, p_succ, p_len, p_ok, p_cnt);
+            const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
+            const float *r_len = (const float *)(hs + p_len);
+            const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
             pool.run(g.live.size(), [&](size_t a, size_t b) {
                 for (size_t k = a; k < b; ++k)
                 {
                     Query &q = Q[g.live[k]];
+                    if (have_results)
+                        D.consume(q, r_ok[k], r_len[k], r_cnt[k], r_succ + k * K);
                     wants[g.live[k]] = (!q.done && D.advance(q)) ? 1 : 0;
                 }
             });
@@ -615,28 +647,18 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     g.keep.push_back(qi);
             g.live.swap(g.keep); // queries that finished drop out
             g.ns = g.live.size();
-            for (size_t s = 0; s < g.ns; ++s)
+            for (size_t k = 0; k < g.ns; ++k)
             {
-                const Query &q = Q[g.live[s]];
+                const Query &q = Q[g.live[k]];
                 const SNode &nd = q.arena[q.cur];
-                h_in[g.s0 + s] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, g.live[s], q.shoot ? 1u : 0u, 0};
+                h_in[g.s0 + k] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, g.live[k], q.shoot ? 1u : 0u, 0};
             }
-            t_pop += now() - t0;
+            t_host += now() - t0;
             return g.ns != 0;
         };
-        // one upload, one launch and one download per round; each group owns a stream and a slice of the
-        // staging block, laid out for the group's current size so the results come back in one copy
-        auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) -> size_t {
-            const size_t cap = (cn + 1) / 2;
-            size_t o = o_succ + (&g - G) * res_stride(cap);
-            p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
-            p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
-            p_ok = o, o += (g.ns + 15) & ~(size_t)15;
-            p_cnt = o, o += (g.ns + 15) & ~(size_t)15;
-            return o - p_succ;
-        };
+        // one upload, one launch and one download per round
         auto launch = [&](Group &g, int gi) -> int {
-            hipStream_t st = c->round_stream[gi][0];
+            hipStream_t st = c->round_stream[gi];
             hipEvent_t *ev = c->round_ev[gi];
             const size_t s0 = g.s0, ns = g.ns;
             const double t0 = now();
@@ -654,46 +676,37 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             t_launch += now() - t0;
             return HYAS_OK;
         };
-        // wait for a group's kernel, then the push phase
-        auto collect = [&](Group &g, int gi) -> int {
+        auto wait = [&](Group &g, int gi) -> int {
             const double t0 = now();
-            HYAS_HIP(c, hipStreamSynchronize(c->round_stream[gi][0]));
+            HYAS_HIP(c, hipStreamSynchronize(c->round_stream[gi]));
             g.inflight = false;
-            const double t1 = now();
-            t_wait += t1 - t0;
+            t_wait += now() - t0;
             float ms = 0;
-            hipEvent_t *ev = c->round_ev[gi];
-            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess)
+            if (hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
                 c->k_ms[0] += ms;
             c->k_launches[0] += 1;
-            size_t p_succ, p_len, p_ok, p_cnt;
-            (void)slice(g, p_succ, p_len, p_ok, p_cnt);
-            const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
-            const float *r_len = (const float *)(hs + p_len);
-            const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
-            pool.run(g.ns, [&](size_t a, size_t b) {
-                for (size_t s = a; s < b; ++s)
-                    D.consume(Q[g.live[s]], r_ok[s], r_len[s], r_cnt[s], r_succ + s * K);
-            });
-            t_push += now() - t1;
             return HYAS_OK;
         };
-        for (int gi = 0; gi < 2; ++gi)
-            if (prepare(G[gi]) && (rc = launch(G[gi], gi)) != HYAS_OK)
+        for (int gi = 0; gi < ng; ++gi)
+            if (host_round(G[gi], false) && (rc = launch(G[gi], gi)) != HYAS_OK)
                 return rc;
-        while (G[0].inflight || G[1].inflight)
-            for (int gi = 0; gi < 2; ++gi)
+        for (bool any = true; any;)
+        {
+            any = false;
+            for (int gi = 0; gi < ng; ++gi)
             {
                 if (!G[gi].inflight)
                     continue;
-                if ((rc = collect(G[gi], gi)) != HYAS_OK)
+                any = true;
+                if ((rc = wait(G[gi], gi)) != HYAS_OK)
                     return rc;
-                if (prepare(G[gi]) && (rc = launch(G[gi], gi)) != HYAS_OK)
+                if (host_round(G[gi], true) && (rc = launch(G[gi], gi)) != HYAS_OK)
                     return rc;
             }
+        }
 
         if (std::getenv("HYAS_TRACE"))
-            fprintf(stderr, "hyas rounds: pop %.3f s, launch %.3f s, wait %.3f s, push %.3f s\n", t_pop, t_launch, t_wait, t_push);
+            fprintf(stderr, "hyas rounds (%d groups): host push+pop %.3f s, launch %.3f s, wait %.3f s\n", ng, t_host, t_launch, t_wait);
         // queries closed by an analytic shot: fetch the curve samples
         // (:160-172: TracePath + the sampled curve + the goal)
         for (size_t i = 0; i < cn; ++i)
