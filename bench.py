@@ -29,43 +29,12 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-def make_queries(ctx, n, rank, W=50, H=50):
-    """n start/goal pairs: x,y uniform in [1, W-1), theta uniform in [0, 2pi), f32; a pose that fails the
-    polygon-mode traversability test is redrawn (rank r draws from its own stream)."""
-    rng = np.random.default_rng(20250228 + 7919 * rank)
-
-    def draw(k):
-        out = np.zeros((0, 3), np.float32)
-        while out.shape[0] < k:
-            m = 2 * k
-            p = np.stack([rng.uniform(1, W - 1, m), rng.uniform(1, H - 1, m), rng.uniform(0, 2 * math.pi, m)], 1).astype(np.float32)
-            ok = ctx.collision(p)
-            out = np.concatenate([out, p[ok == 1]])
-        return out[:k].copy()
-
-    return draw(n), draw(n)
-
-
 def algorithmic_bytes(st):
-    """Bytes the step kernel has to move for the work in `st` (hyas_get_stats): per expanded node 20 B in; per emitted
+    """Bytes the round kernel has to move for the work in `st` (hyas_get_stats): per expanded node 20 B in; per emitted
     successor 28 B out + 4 B table + 4 B 2D-cost read; per collision-tested successor / curve sample 12 B pose and
     32 B (4 vertices x 8 B) per obstacle-list entry walked; 1 bit verdict per sample."""
     return (20 * st["nodes"] + 36 * st["succ_emitted"] + 12 * st["succ_evaluated"] + 32 * st["succ_list_entries"]
             + 12 * st["samples_serial"] + 32 * st["sample_list_entries"] + st["samples_serial"] // 8)
-
-
-def aggregate(dist, local_seconds, local_counts):
-    """MAX of the ranks' times and SUM of their work counters (torch.distributed, any backend)."""
-    import torch
-
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local_seconds, list(local_counts)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([local_seconds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    c = torch.tensor(list(local_counts), dtype=torch.float64, device=dev)
-    dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    return float(t.item()), [float(v) for v in c.tolist()]
 
 
 def cpu_baseline(map_arr, starts, goals, budget_s=15.0):
@@ -112,6 +81,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the expansion path has no CPU fallback")
 
     from path_planner_amd import Hyas, hot_path_params
+    from path_planner_amd.sharding import aggregate, make_queries
     import orc  # only for the map fixture loader and the cpu_baseline leg
 
     map_arr = orc.load_map("map_maze")
@@ -120,7 +90,8 @@ def main():
     ctx.set_costmap(map_arr, build_table=True)
     setup_s = time.time() - t0
     table_ms, _ = ctx.kernel_ms(3)
-    starts, goals = make_queries(ctx, args.queries, rank)
+    # rank r draws its own 1024 queries (weak scaling); rank 0 uses the seed the workload is defined with
+    starts, goals = make_queries(ctx.collision, args.queries, 20250228 + 7919 * rank, 50, 50)
 
     def barrier():
         if dist is not None:
@@ -136,7 +107,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = ctx.plan_batch(starts, goals)
-        ms, nl = ctx.kernel_ms(0)  # HIP events on the library's stream, accumulated per launch
+        ms, nl = ctx.kernel_ms(0)  # HIP events on the streams the round kernel is launched on, summed over launches
         kern_ms += ms
         kern_launches += nl
     barrier()
@@ -167,7 +138,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_step_rs", "avg_launch_us": avg_ms * 1e3,
+                    "traffic": traffic, "kernel": "k_round", "avg_launch_us": avg_ms * 1e3,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": launches_1,
                     "note": "map, obstacle lists and tables are <= 30 MB and cache-resident: HBM fraction is low by "
                             "construction; the kernel is bound by f32/f64 ALU and L2/L1 latency"}

@@ -1,0 +1,72 @@
+// Test scaffolding, never shipped: the product's device geometry (hyas_dev.h)
+// and list pruning (hyas_prune.h) compiled for the host, so the CPU test suite
+// can compare the exact code the kernels run against the oracle on adversarial
+// poses without a GPU.  The product library has no such path.
+#include <cmath>
+#include <vector>
+
+#include "../../path_planner_amd/csrc/hyas_dev.h"
+#include "../../path_planner_amd/csrc/hyas_prune.h"
+
+using namespace hyas;
+
+// quads8: nq x 4 vertices (x, y); lists are rebuilt here from the quads with the
+// reference's range rule (src/collisiondetection.cpp:319-354); verdict = on-grid
+// && pose test && (pred ? swept-segment test : true).  prune = 0 walks the full
+// per-cell lists with culling disabled.
+extern "C" int hg_collision(const float *quads8, int nq, const uint8_t *charmap, int w, int h, float veh_len, float veh_wid, float range,
+                            const float *xyt, const float *pred, int n, uint8_t *out, int prune, uint32_t *entries /* [3] */)
+{
+    std::vector<Quad> Q(nq);
+    for (int i = 0; i < nq; i++)
+    {
+        Quad &q = Q[i];
+        for (int k = 0; k < 4; k++)
+            q.vx[k] = quads8[i * 8 + 2 * k], q.vy[k] = quads8[i * 8 + 2 * k + 1];
+        q.xmin = q.xmax = q.vx[0], q.ymin = q.ymax = q.vy[0];
+        for (int k = 1; k < 4; k++)
+        {
+            q.xmin = std::fmin(q.xmin, q.vx[k]), q.xmax = std::fmax(q.xmax, q.vx[k]);
+            q.ymin = std::fmin(q.ymin, q.vy[k]), q.ymax = std::fmax(q.ymax, q.vy[k]);
+        }
+        q.axis_rect = (q.vx[0] == q.xmin && q.vy[0] == q.ymin && q.vx[1] == q.xmax && q.vy[1] == q.ymin && q.vx[2] == q.xmax &&
+                       q.vy[2] == q.ymax && q.vx[3] == q.xmin && q.vy[3] == q.ymax && q.xmin < q.xmax && q.ymin < q.ymax);
+    }
+    std::vector<uint32_t> off(w * h + 1);
+    std::vector<uint16_t> idx;
+    for (int key = 0; key < w * h; key++)
+    {
+        off[key] = (uint32_t)idx.size();
+        const float x = (float)(key % w), y = (float)(key / w);
+        for (int q = 0; q < nq; q++)
+            if (dist_quad_point(Q[q], f2(x, y)) < range)
+                idx.push_back((uint16_t)q);
+    }
+    off[w * h] = (uint32_t)idx.size();
+    DevMap m{};
+    m.charmap = charmap, m.w = w, m.h = h, m.res = 1, m.ox = 0, m.oy = 0, m.res_f = 1, m.ox_f = 0, m.oy_f = 0;
+    m.res_pow2 = 1, m.inv_res = 1, m.inv_res_f = 1;
+    m.quads = Q.data(), m.n_quads = nq, m.cell_off = off.data(), m.cell_idx = idx.data();
+    m.veh_len = veh_len, m.veh_wid = veh_wid, m.half_wid = 0.5 * (double)veh_wid;
+    m.cull_margin = prune ? (float)(0.01 + 2e-3 * std::sqrt((double)w * w + (double)h * h)) : 1e9f;
+    std::vector<uint32_t> po, so;
+    std::vector<uint16_t> pi, si;
+    const float lmax = 0.3f;
+    prune_lists(m, Q.data(), off.data(), idx.data(), lmax, po, pi, so, si);
+    m.pose_off = po.data(), m.pose_idx = pi.data(), m.seg_off = so.data(), m.seg_idx = si.data();
+    m.seg_lmax = prune ? lmax : 0.f;
+    if (!prune)
+        m.pose_off = off.data(), m.pose_idx = idx.data();
+    if (entries)
+        entries[0] = (uint32_t)idx.size(), entries[1] = (uint32_t)pi.size(), entries[2] = (uint32_t)si.size();
+    const GlobalQuads gq{Q.data()};
+    for (int i = 0; i < n; i++)
+    {
+        const float x = xyt[3 * i], y = xyt[3 * i + 1], t = xyt[3 * i + 2];
+        bool ok = on_grid(m, x, y) && pose_free(m, gq, x, y, t);
+        if (ok && pred)
+            ok = segment_free(m, gq, x, y, pred[2 * i], pred[2 * i + 1]);
+        out[i] = ok ? 1 : 0;
+    }
+    return 0;
+}

@@ -281,6 +281,14 @@ class Oracle:
                                out.ctypes.data_as(C.c_void_p))
         return rc, out
 
+    def dubins_sample(self, q0, q1, rho, t):
+        a = np.asarray(q0, np.float32)
+        b = np.asarray(q1, np.float32)
+        q = np.zeros(3, np.float32)
+        rc = self.L.orc_dubins_sample(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_float(rho), C.c_float(t),
+                                      q.ctypes.data_as(C.c_void_p))
+        return rc, q
+
     def utility(self, op, args):
         a = np.asarray(args, np.float32)
         return self.L.orc_utility(int(op), a.ctypes.data_as(C.c_void_p))

@@ -221,3 +221,27 @@ def test_resolution_and_origin(oracle_built):
     assert np.array_equal(p.o.collision(xyt, pred), p.h.collision(xyt, pred))
     s, g = p.free_poses(16, 72), p.free_poses(16, 73)
     _plan_compare(p, s, g)
+
+
+def test_plan_golden_fixture():
+    """The committed end-to-end vectors (tests/golden/plan_golden.npz, made by the CPU oracle): status, counters,
+    ordered expanded-node indices and path poses from the GPU path, bit for bit."""
+    from pathlib import Path
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "plan_golden.npz")
+    by_map = {}
+    for name in g["names"]:
+        by_map.setdefault((str(g[f"{name}/map"]), int(g[f"{name}/pr"][0])), []).append(str(name))
+    for (mp, pr), names in by_map.items():
+        _, ph = _params(position_resolution=pr)
+        h = Hyas(ph)
+        h.set_costmap(orc.load_map(mp), build_table=True)
+        s = np.stack([g[f"{n}/start"] for n in names]).astype(np.float32)
+        t = np.stack([g[f"{n}/goal"] for n in names]).astype(np.float32)
+        res = h.plan_batch(s, t)
+        for i, n in enumerate(names):
+            assert res[i].tobytes() == g[f"{n}/result"].tobytes(), (n, res[i], g[f"{n}/result"])
+            assert np.array_equal(h.expanded(i), g[f"{n}/expanded"]), n
+            assert h.path(i).tobytes() == g[f"{n}/path"].tobytes(), n
+            # path cost within 1e-6 relative is implied by the bitwise match; stated for the record
+            assert abs(float(res[i]["g_final"]) - float(g[f"{n}/result"]["g_final"])) <= 1e-6 * max(1.0, float(res[i]["g_final"]))

@@ -1,0 +1,103 @@
+"""CPU suite: host-side logic of the product.
+
+The device geometry header and the list pruning are compiled for the host
+(tests/host_geom, test scaffolding) and compared with the oracle on adversarial
+poses: points on vertex rows and columns, within 1e-3 of cell borders,
+horizontal segments through vertex rows, long segments that bypass pruning.
+The planner mirror's argument handling is checked without a device."""
+import ctypes as C
+import math
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = Path(__file__).resolve().parent.parent
+HG = ROOT / "tests" / "host_geom"
+
+
+@pytest.fixture(scope="module")
+def host_geom():
+    so, src = HG / "libhost_geom.so", HG / "host_geom.cpp"
+    deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h"]
+    if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
+                        "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
+    return C.CDLL(str(so))
+
+
+def adversarial(W, H, n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, W, n)
+    y = rng.uniform(0, H, n)
+    t = rng.uniform(0, 2 * math.pi, n)
+    k = n // 3
+    eps = [0, 1e-4, -1e-4, 5e-4, -9e-4, 2e-3]
+    y[:k] = np.round(y[:k]) + rng.choice(eps, k)  # vertex rows
+    x[k:2 * k] = np.round(x[k:2 * k]) + rng.choice(eps, k)  # vertex columns
+    xyt = np.stack([x, y, t], 1).astype(np.float32)
+    d = rng.uniform(0.02, 0.3, n)
+    a = rng.uniform(0, 2 * math.pi, n)
+    pred = (xyt[:, :2] + np.stack([d * np.cos(a), d * np.sin(a)], 1)).astype(np.float32)
+    pred[:k:2, 1] = xyt[:k:2, 1]  # horizontal segments on vertex rows
+    m = len(xyt[k::5])
+    pred[k::5] = xyt[k::5, :2] + rng.uniform(-3, 3, (m, 2)).astype(np.float32)  # long segments: unpruned lists
+    return xyt, pred
+
+
+@pytest.mark.parametrize("map_name", ["map_parking", "map_maze", "map_large", "map_slalom"])
+def test_device_geometry_and_pruning_match_oracle(map_name, host_geom, oracle_built):
+    mp = orc.load_map(map_name)
+    H, W = mp.shape
+    o = orc.Oracle(orc.hot_path_params(position_resolution=1))
+    o.set_costmap(mp, build_table=False)
+    Q = np.ascontiguousarray(o.obstacles(), np.float32)
+    xyt, pred = adversarial(W, H, 60000, 7)
+    want = o.collision(xyt, pred)
+    want_pose = o.collision(xyt)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    ent = np.zeros(3, np.uint32)
+    for prune in (1, 0):
+        got = np.zeros(len(xyt), np.uint8)
+        host_geom.hg_collision(vp(Q), len(Q), vp(mp), W, H, C.c_float(2), C.c_float(1), C.c_float(5), vp(xyt), vp(pred), len(xyt),
+                               vp(got), prune, vp(ent))
+        assert int((got != want).sum()) == 0, (map_name, prune)
+        got2 = np.zeros(len(xyt), np.uint8)
+        host_geom.hg_collision(vp(Q), len(Q), vp(mp), W, H, C.c_float(2), C.c_float(1), C.c_float(5), vp(xyt), None, len(xyt),
+                               vp(got2), prune, vp(ent))
+        assert int((got2 != want_pose).sum()) == 0, (map_name, prune)
+    assert 0.02 < want.mean() < 0.98
+    assert ent[1] <= ent[0] and ent[2] <= 2 * ent[0]  # pruning never adds pose entries
+
+
+def test_posestamped_yaw_round_trip():
+    from path_planner_amd.planner import PoseStamped
+
+    for yaw in (0.0, 0.3, math.pi / 2, math.pi, 4.0, 2 * math.pi - 1e-3):
+        p = PoseStamped.from_yaw(1.5, -2.0, yaw)
+        assert abs(((p.yaw() - yaw + math.pi) % (2 * math.pi)) - math.pi) < 1e-6
+        assert p.x == 1.5 and p.y == -2.0 and p.frame_id == "map"
+
+
+def test_costmap_accessors():
+    from path_planner_amd.planner import Costmap2D
+
+    m = np.zeros((30, 60), np.uint8)
+    c = Costmap2D(m, resolution=0.5, origin_x=1.0, origin_y=-2.0)
+    assert c.getSizeInCellsX() == 60 and c.getSizeInCellsY() == 30
+    assert c.getResolution() == 0.5 and c.getOriginX() == 1.0 and c.getOriginY() == -2.0
+    assert c.getCharMap().shape == (30, 60)
+
+
+def test_make_plan_before_initialize_returns_false():
+    """src/hybrid_a_star_planner.cpp:101-105: an uninitialised planner refuses, it does not throw."""
+    from path_planner_amd.planner import HybridAStarPlanner, PoseStamped
+
+    pl = HybridAStarPlanner()
+    plan = ["stale"]
+    assert pl.makePlan(PoseStamped.from_yaw(1, 1, 0), PoseStamped.from_yaw(2, 2, 0), plan) is False
+    with pytest.raises(RuntimeError):
+        pl.makePlanBatch(np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32))

@@ -1,0 +1,254 @@
+"""CPU suite: the oracle against every fixed answer the reference holds for the
+expansion path, and against vectors produced by the reference's own Dubins
+source compiled as is (tests/golden/make_dubins_golden.py).
+
+Utility op codes of orc_utility (oracle/oracle.cpp), all arguments float32:
+ 0 IsIntersect(p1,p2,p3,p4)              1 FindIntersectionPoint -> x*1e5+y
+ 2 OnSegment(a,b,p)                      3 IsAboveSegment(a,b,p)
+ 4 IsInsidePolygon(quad v0..v3, p)       5 GetDistanceFromPolygonToPoint(CreatePolygon(o), p)
+ 6 GetDistanceFromSegmentToPoint(a,b,p)  7 CreatePolygon(center,w,h,heading)[i].x
+ 8 IsPolygonIntersectWithPolygon(CreatePolygon(o1), CreatePolygon(o2))
+ 9 GetDistanceFromPolygonToSegment(CreatePolygon(o), a, b)
+10 CombinePolygon(CreatePolygon(o1), CreatePolygon(o2)).size()
+11 IsSegmentIntersectWithPolygon(CreatePolygon(o), a, b)
+12 GetUnitVector(a,b) -> x*10+y          13 IsPointOnLine(p, start, unit)
+14 GetDistanceFromPointToLine(p, start, unit)
+15 RadToZeroTo2P  16 RadNormalization  17 ConvertDegToRad
+Only the Utility functions the fixed-step expansion path reaches are covered; the
+angle-range algebra of test/test.cpp belongs to the adaptive step-size code.
+"""
+import ctypes as C
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import orc
+
+GOLD = Path(__file__).resolve().parent / "golden"
+KAT = json.loads((GOLD / "kat.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def ora(oracle_built):
+    return orc.Oracle(orc.hot_path_params())
+
+
+@pytest.fixture(scope="module")
+def ora_libm(oracle_built):
+    return orc.Oracle(orc.hot_path_params(), libm=True)
+
+
+@pytest.mark.parametrize("case", KAT["utility"], ids=[c["name"] for c in KAT["utility"]])
+@pytest.mark.parametrize("flavour", ["portable", "libm"])
+def test_utility_known_answers(case, flavour, ora, ora_libm):
+    o = ora if flavour == "portable" else ora_libm
+    got = o.utility(case["op"], case["args"])
+    if case["tol"] == 0:
+        assert got == case["expect"], case["ref"]
+    else:
+        assert abs(got - case["expect"]) <= case["tol"] * max(1.0, abs(case["expect"])), (got, case["ref"])
+
+
+@pytest.mark.parametrize("case", KAT["reeds_shepp"])
+def test_reeds_shepp_known_lengths(case, ora, ora_libm):
+    for o in (ora, ora_libm):
+        got = o.rs_distance(case["rho"], case["q0"], case["q1"])
+        assert abs(got - case["length"]) <= case["tol"] * max(1.0, case["length"])
+
+
+def test_reeds_shepp_symmetries(ora):
+    """Properties of the RS metric the word families guarantee: symmetric in its
+    arguments, zero on identical states, scales with rho."""
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        a = [rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(0, 2 * math.pi)]
+        b = [rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(0, 2 * math.pi)]
+        d1 = ora.rs_distance(1.0, a, b)
+        d2 = ora.rs_distance(1.0, b, a)
+        assert abs(d1 - d2) <= 1e-9 * max(1.0, d1)
+        d3 = ora.rs_distance(2.0, [2 * v if i < 2 else v for i, v in enumerate(a)], [2 * v if i < 2 else v for i, v in enumerate(b)])
+        assert abs(d3 - 2 * d1) <= 1e-9 * max(1.0, d3)
+        assert d1 >= math.hypot(a[0] - b[0], a[1] - b[1]) - 1e-9
+    assert ora.rs_distance(1.0, [1, 2, 3], [1, 2, 3]) == 0.0
+
+
+def test_reeds_shepp_sampling_reaches_goal(ora):
+    """interpolate() at the full length lands on the goal; samples are step apart."""
+    rng = np.random.default_rng(12)
+    for _ in range(100):
+        a = [rng.uniform(0, 30), rng.uniform(0, 30), rng.uniform(0, 2 * math.pi)]
+        b = [rng.uniform(0, 30), rng.uniform(0, 30), rng.uniform(0, 2 * math.pi)]
+        length, pts = ora.rs_sample(6.0, a, b, 0.1)
+        assert len(pts) > 0
+        d = np.hypot(np.diff(pts[:, 0]), np.diff(pts[:, 1]))
+        assert d.max() <= 0.1 + 1e-9
+        assert math.hypot(pts[-1, 0] - b[0], pts[-1, 1] - b[1]) <= 0.1 + 1e-6
+
+
+def test_rs_table_checksum(ora):
+    """Sum of the 131 327 Reeds-Shepp costs of the 60x30, position_resolution 1, rho 0.35 table
+    (loops of src/lookup_table.cpp:182-224; x = y = 0 skipped) against the figure recorded from
+    the in-tree src/ReedsShepp.cpp.  Summation order differs, hence 1e-12 relative."""
+    t = KAT["rs_table"]
+    dh = np.float32(2 * math.pi / 72)
+    th = np.float32(0)
+    ts = []
+    while th < 2 * math.pi:  # float accumulation, 73 samples
+        ts.append(float(th))
+        th = np.float32(th + dh)
+    assert len(ts) == 73
+    s = 0.0
+    n = 0
+    for tt in ts:
+        for y in range(t["h"]):
+            for x in range(t["w"]):
+                if x == 0 and y == 0:
+                    continue
+                s += ora.rs_distance(t["rho"], (0, 0, 0), (x, y, tt))
+                n += 1
+    assert n == t["entries"]
+    assert abs(s - t["sum"]) <= 1e-12 * t["sum"]
+
+
+def test_rs_table_build_matches_rs_distance(oracle_built):
+    """The table builder stores float(rs distance) under the reference's key and keeps the first write."""
+    o = orc.Oracle(orc.hot_path_params(position_resolution=1, cd_min_turning_radius=0.35))
+    o.set_costmap(orc.load_map("map_parking"), build_table=True, nthreads=8)
+    raw = o.table_build(1, 0, 73)
+    assert raw.shape == (73, 30, 60)
+    rng = np.random.default_rng(5)
+    dh = np.float32(2 * math.pi / 72)
+    ts = [np.float32(0)]
+    for _ in range(72):
+        ts.append(np.float32(ts[-1] + dh))
+    for _ in range(500):
+        k, j, i = int(rng.integers(0, 73)), int(rng.integers(0, 30)), int(rng.integers(0, 60))
+        want = o.rs_distance(0.35, (0, 0, 0), (i, j, float(ts[k])))
+        assert abs(float(raw[k, j, i]) - want) <= 2.4e-7 * max(1.0, want)  # one float32 rounding
+    s, n = o.table_checksum()
+    assert n == 129528  # 60*30*72 keys minus the 72 skipped x = y = 0 entries
+    # lookups: a present key returns the stored cost, an absent one the miss value (src/lookup_table.cpp:100-122)
+    q = np.array([[3, 2, 1.0], [0.2, 0.3, 0.0], [59, 29, 6.2]], np.float32)
+    c = o.table_lookup(q)
+    assert c[1] == np.float32(1e8)
+    assert np.isfinite(c).all() and c[0] < 1e6
+
+
+def test_footprint_table_pins(oracle_built):
+    """Entry count, total and maximum cell count of the footprint table with the in-tree
+    constants (include/lookup.h:30-284, include/constants.h:35-80)."""
+    o = orc.Oracle(orc.default_params())
+    o.set_costmap(orc.load_map("map_parking"), build_table=False)
+    fp = o.footprint_table()
+    pin = KAT["footprint"]
+    assert fp.shape == (pin["entries"], 129)
+    assert int(fp[:, 0].sum()) == pin["sum_len"]
+    assert int(fp[:, 0].max()) == pin["max_len"]
+    assert int(fp[:, 0].min()) >= 1
+
+
+def _dubins_gold():
+    return np.load(GOLD / "dubins_golden.npz")
+
+
+def test_dubins_against_reference_vectors_libm(ora_libm):
+    """libm flavour of the restatement == the reference's src/dubins.cpp (compiled as is) bit for bit:
+    word type, the three segment lengths, the path length and eight samples, 4096 cases."""
+    g = _dubins_gold()
+    n = len(g["q0"])
+    for i in range(n):
+        rc, out = ora_libm.dubins(g["q0"][i], g["q1"][i], float(g["rho"][i]))
+        assert rc == g["rc"][i]
+        if rc != 0:
+            continue
+        assert int(out[0]) == g["type"][i], i
+        assert out[1:4].tobytes() == g["param"][i].tobytes(), i
+        assert out[4].tobytes() == g["length"][i].tobytes(), i
+    for i in range(0, n, 8):
+        for k in range(8):
+            t = np.float32(g["length"][i] * np.float32(k) / np.float32(8))
+            rc, q = ora_libm.dubins_sample(g["q0"][i], g["q1"][i], float(g["rho"][i]), float(t))
+            assert rc == g["sample_rc"][i, k]
+            assert q.tobytes() == g["samples"][i, k].tobytes(), (i, k)
+
+
+def test_dubins_against_reference_vectors_portable(ora):
+    """The portable-math flavour (the one the GPU is compared with) differs from libm by rounding of
+    sinf/cosf/atan2f/acosf only: same word except at ties, lengths within a few ulp."""
+    g = _dubins_gold()
+    n = len(g["q0"])
+    same_type = 0
+    worst = 0.0
+    for i in range(n):
+        rc, out = ora.dubins(g["q0"][i], g["q1"][i], float(g["rho"][i]))
+        assert rc == g["rc"][i]
+        same_type += int(out[0]) == g["type"][i]
+        worst = max(worst, abs(float(out[4]) - float(g["length"][i])) / max(1.0, float(g["length"][i])))
+    assert same_type >= n - 4
+    assert worst <= 2e-5
+
+
+def test_dubins_live_reference_if_built(ora_libm):
+    """When oracle/_ref/libdubins_ref.so is present (built from the reference tree by oracle/Makefile), fresh
+    random cases go through both."""
+    ref = orc.ORACLE_DIR / "_ref" / "libdubins_ref.so"
+    if not ref.exists():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+
+    class DubinsPath(C.Structure):
+        _fields_ = [("qi", C.c_float * 3), ("param", C.c_float * 3), ("rho", C.c_float), ("type", C.c_int)]
+
+    lib = C.CDLL(str(ref))
+    init = getattr(lib, "_ZN11HybridAStar11dubins_initEPfS0_fPNS_10DubinsPathE")
+    init.restype = C.c_int
+    length = getattr(lib, "_ZN11HybridAStar18dubins_path_lengthEPNS_10DubinsPathE")
+    length.restype = C.c_float
+    rng = np.random.default_rng(99)
+    fp = C.POINTER(C.c_float)
+    for _ in range(2000):
+        a = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(0, 2 * math.pi)], np.float32)
+        b = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(0, 2 * math.pi)], np.float32)
+        rho = float(rng.choice([0.35, 1.0, 6.0]))
+        p = DubinsPath()
+        rc = init(a.ctypes.data_as(fp), b.ctypes.data_as(fp), C.c_float(rho), C.byref(p))
+        rc2, out = ora_libm.dubins(a, b, rho)
+        assert rc == rc2
+        if rc == 0:
+            assert int(out[0]) == p.type
+            assert np.float32(length(C.byref(p))).tobytes() == out[4].tobytes()
+
+
+def test_libm_gap_is_small(oracle_built):
+    """How far the two flavours of the restatement are apart on collision verdicts: the portable math
+    rounds sinf/cosf differently in about 1 % of calls, which flips a verdict only when a vehicle corner
+    lands within an ulp of an obstacle edge."""
+    mp = orc.load_map("map_maze")
+    a = orc.Oracle(orc.hot_path_params())
+    b = orc.Oracle(orc.hot_path_params(), libm=True)
+    a.set_costmap(mp, build_table=False)
+    b.set_costmap(mp, build_table=False)
+    rng = np.random.default_rng(3)
+    n = 50000
+    p = np.stack([rng.uniform(0, 50, n), rng.uniform(0, 50, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
+    va, vb = a.collision(p), b.collision(p)
+    assert (va != vb).sum() <= 5
+
+
+def test_plan_golden_regression(oracle_built):
+    """End-to-end search outputs of the restatement are stable (tests/golden/make_plan_golden.py): result record,
+    ordered expanded-node indices and path poses, bit for bit."""
+    g = np.load(GOLD / "plan_golden.npz")
+    ctx = {}
+    for name in g["names"]:
+        mp, pr = str(g[f"{name}/map"]), int(g[f"{name}/pr"][0])
+        if (mp, pr) not in ctx:
+            o = orc.Oracle(orc.hot_path_params(position_resolution=pr))
+            o.set_costmap(orc.load_map(mp), build_table=True, nthreads=8)
+            ctx[(mp, pr)] = o
+        res, path, exp = ctx[(mp, pr)].plan(g[f"{name}/start"], g[f"{name}/goal"])
+        assert res.tobytes() == g[f"{name}/result"].tobytes(), name
+        assert np.array_equal(exp, g[f"{name}/expanded"]), name
+        assert path.tobytes() == g[f"{name}/path"].tobytes(), name
