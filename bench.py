@@ -64,7 +64,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="queries_maze",
+                    choices=["queries_maze", "queries_large", "footprint_checks", "rs_table"],
+                    help="queries_maze is the benchmark the metric is quoted on; the others are the remaining configurations")
+    ap.add_argument("--table-pr", type=int, default=1, help="rs_table: position_resolution (1 or 10)")
     args = ap.parse_args()
+    if args.workload != "queries_maze":
+        import bench_extra
+
+        return bench_extra.run(args)
 
     import torch
 

@@ -1,0 +1,220 @@
+"""The benchmark configurations besides the headline one (bench.py --workload ...):
+
+ footprint_checks  4096 x 4096 random-occupancy grid (10 % occupied), 10 M footprint-list collision checks
+                   per GPU per step, poses resident in HBM;
+ rs_table          Reeds-Shepp heuristic table of a 180 x 60 map (rho 0.35), heading slices sharded over the
+                   GPUs and assembled with one all-gather, then installed on every GPU;
+ queries_large     65 536 planning queries on maps/map_large sharded over the GPUs (strong scaling).
+
+Same output contract as bench.py: one JSON line on rank 0.
+"""
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+HBM_PEAK_GBS = 8000.0
+
+
+def _dist_setup():
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU: the expansion path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return torch, dist, rank, local_rank, world
+
+
+def _barrier(torch, dist):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def footprint_checks(args):
+    torch, dist, rank, local_rank, world = _dist_setup()
+    from path_planner_amd import Hyas, default_params
+    from path_planner_amd._lib import MODE_FOOTPRINT
+    from path_planner_amd.sharding import aggregate
+
+    W = H = 4096
+    n = 10_000_000
+    grid = np.where(np.random.default_rng(1).random((H, W)) < 0.10, 254, 0).astype(np.uint8)
+    rng = np.random.default_rng(2 + 7919 * rank)
+    xyt = np.stack([rng.uniform(8, W - 8, n), rng.uniform(8, H - 8, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
+    ctx = Hyas(default_params(), device=local_rank)  # in-tree footprint constants: 7200 lists of at most 4 cells
+    ctx.set_grid(grid)
+    fp_len = ctx.footprint_table()[:, 0]
+    d_xyt = torch.from_numpy(xyt).cuda()
+    d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        ctx.collision_dev(d_xyt.data_ptr(), None, n, d_out.data_ptr(), MODE_FOOTPRINT)
+    _barrier(torch, dist)
+    ctx.reset_kernel_timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.collision_dev(d_xyt.data_ptr(), None, n, d_out.data_ptr(), MODE_FOOTPRINT)
+    _barrier(torch, dist)
+    local_s = time.perf_counter() - t0
+    kms, kl = ctx.kernel_ms(2)
+    free = int(d_out.sum().item())
+    total_s, (checks,) = aggregate(dist, local_s, [float(n) * args.steps])
+    if rank != 0:
+        return None
+    # algorithmic bytes: 12 B pose + 1 B verdict + one grid byte per footprint cell visited
+    it = (xyt[:, 2] / np.float32(2 * math.pi / 72)).astype(np.int64).clip(0, 71)
+    ix = ((xyt[:, 0] - np.floor(xyt[:, 0])) * 10).astype(np.int64).clip(0, 9)
+    iy = ((xyt[:, 1] - np.floor(xyt[:, 1])) * 10).astype(np.int64).clip(0, 9)
+    mean_len = float(fp_len[(iy * 10 + ix) * 72 + it].mean())
+    bytes_per_launch = n * (13.0 + mean_len)
+    avg_ms = kms / max(kl, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import orc
+
+        o = orc.Oracle(orc.default_params())
+        o.set_grid(grid)
+        m = 2_000_000
+        t0 = time.perf_counter()
+        ref = o.collision(xyt[:m], mode=1)
+        cs = time.perf_counter() - t0
+        same = bool(np.array_equal(ref, d_out[:m].cpu().numpy()))
+        cpu = {"value": m / cs, "unit": "checks/s", "cores": 1, "kind": "port",
+               "sample": f"first {m} of the {n} poses on one thread ({cs:.2f} s); verdicts equal to the GPU's: {same}"}
+    return {
+        "metric": "footprint collision checks/sec", "value": checks / total_s, "unit": "checks/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+        "config": {"workload": "4096x4096 grid, 10 % occupied, 10M footprint-list checks per GPU, in-tree 0.22x0.18 m footprint",
+                   "free_fraction_rank0": free / n, "mean_cells_per_check": mean_len},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_collision_footprint", "avg_launch_us": avg_ms * 1e3,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        "cpu_baseline": cpu,
+    }
+
+
+def rs_table(args):
+    torch, dist, rank, local_rank, world = _dist_setup()
+    from path_planner_amd import Hyas, hot_path_params
+    from path_planner_amd.sharding import aggregate, build_table_sharded
+
+    pr = args.table_pr
+    grid = np.zeros((60, 180), np.uint8)
+    ctx = Hyas(hot_path_params(position_resolution=pr, cd_min_turning_radius=0.35), device=local_rank)
+    ctx.set_costmap(grid, build_table=False)
+    nx, ny, ns = ctx.table_dims()
+    entries = nx * ny * ns
+    parts = [0.0, 0.0, 0.0]
+    for _ in range(args.warmup):
+        build_table_sharded(ctx, 1, dist)
+    _barrier(torch, dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b, g, i = build_table_sharded(ctx, 1, dist)
+        parts[0] += b
+        parts[1] += g
+        parts[2] += i
+    _barrier(torch, dist)
+    local_s = time.perf_counter() - t0
+    total_s, _ = aggregate(dist, local_s, [0.0])
+    # spot-check: the installed table answers lookups
+    probe = np.array([[3.0, 2.0, 1.0], [100.0, 40.0, 3.0]], np.float32)
+    cost = ctx.table_lookup(probe)
+    if rank != 0:
+        return None
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import orc
+
+        o = orc.Oracle(orc.hot_path_params(position_resolution=pr, cd_min_turning_radius=0.35))
+        o.set_costmap(grid, build_table=False)
+        k1 = 1 if pr > 1 else 8
+        t0 = time.perf_counter()
+        o.table_build(1, 0, k1)
+        cs = time.perf_counter() - t0
+        cpu = {"value": k1 * nx * ny / cs, "unit": "entries/s", "cores": 1, "kind": "port",
+               "sample": f"{k1} of the {ns} heading slices on one thread ({cs:.2f} s)"}
+    per_build = total_s / args.steps
+    return {
+        "metric": "Reeds-Shepp heuristic table entries/sec", "value": entries / per_build, "unit": "entries/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * per_build, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"180x60 map, position_resolution {pr}, rho 0.35: {entries} entries, {ns} heading slices over {world} GPU(s)",
+                   "seconds_build_gather_install_rank0": [p / args.steps for p in parts], "probe_costs": [float(v) for v in cost]},
+        "roofline": {"bound": "hbm", "achieved": 4.0 * entries / (parts[0] / args.steps) / 1e9 if parts[0] > 0 else 0.0,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 4.0 * entries / (parts[0] / args.steps) / 1e9 / HBM_PEAK_GBS if parts[0] > 0 else 0.0,
+                     "traffic": None, "kernel": "k_table_rs",
+                     "note": "4 B stored per entry; the kernel is f64 ALU bound (44 closed-form candidates per entry), the HBM fraction is low by construction"},
+        "cpu_baseline": cpu,
+    }
+
+
+def queries_large(args):
+    torch, dist, rank, local_rank, world = _dist_setup()
+    sys.path.insert(0, str(ROOT / "tests"))
+    import orc  # map fixture loader only
+    from path_planner_amd import Hyas, hot_path_params
+    from path_planner_amd.sharding import aggregate, make_queries, query_shard
+
+    total_q = args.queries if args.queries != 1024 else 65536
+    mp = orc.load_map("map_large")
+    H, W = mp.shape
+    ctx = Hyas(hot_path_params(), device=local_rank)
+    ctx.set_costmap(mp, build_table=True)
+    starts, goals = make_queries(ctx.collision, total_q, 3, W, H)  # every rank draws the same batch, then takes its block
+    b, e = query_shard(total_q, rank, world)
+    starts, goals = starts[b:e], goals[b:e]
+    for _ in range(args.warmup):
+        ctx.plan_batch(starts[: min(len(starts), 2048)], goals[: min(len(goals), 2048)])
+    _barrier(torch, dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = ctx.plan_batch(starts, goals)
+    _barrier(torch, dist)
+    local_s = time.perf_counter() - t0
+    kms, kl = ctx.kernel_ms(0)
+    succ = float(res["successors"].sum()) * args.steps
+    expd = float(res["nodes_expanded"].sum()) * args.steps
+    total_s, (succ, expd, nq) = aggregate(dist, local_s, [succ, expd, float(len(res)) * args.steps])
+    if rank != 0:
+        return None
+    status = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
+    return {
+        "metric": "collision-checked node expansions/sec", "value": succ / total_s, "unit": "successors/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"map_large 180x60, {total_q} queries in contiguous blocks over {world} GPU(s), Reeds-Shepp shot every pop"},
+        "queries_per_s": nq / total_s, "nodes_expanded_per_s": expd / total_s, "status_counts_rank0": status,
+        "round_kernel_avg_us_rank0": 1e3 * kms / max(kl, 1),
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
+def run(args):
+    fn = {"footprint_checks": footprint_checks, "rs_table": rs_table, "queries_large": queries_large}[args.workload]
+    line = fn(args)
+    if line is not None:
+        print(json.dumps(line))
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

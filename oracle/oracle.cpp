@@ -1907,6 +1907,17 @@ int orc_set_costmap(void *h, const uint8_t *charmap, uint32_t w, uint32_t hgt, d
     return 0;
 }
 
+// Grid for the footprint-list test only (any size): no obstacle polygons, no lists, no tables.
+int orc_set_grid(void *h, const uint8_t *charmap, uint32_t w, uint32_t hgt)
+{
+    Ctx *c = (Ctx *)h;
+    c->cm.w = w, c->cm.h = hgt, c->cm.res = 1, c->cm.ox = 0, c->cm.oy = 0;
+    c->cm.cost.assign(charmap, charmap + (size_t)w * hgt);
+    c->resolution_ = 1, c->origin_x_ = 0, c->origin_y_ = 0;
+    c->buildFootprintTable();
+    return 0;
+}
+
 int orc_num_obstacles(void *h) { return (int)((Ctx *)h)->obstacle_vec_.size(); }
 // 8 floats per obstacle: the 4 distinct vertices
 int orc_get_obstacles(void *h, float *out, size_t cap)

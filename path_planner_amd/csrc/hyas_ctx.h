@@ -42,6 +42,8 @@ struct hyas_ctx
     uint32_t *d_cell_off = nullptr;
     uint16_t *d_cell_idx = nullptr;
     int32_t *d_fp = nullptr;
+    uint64_t *d_occ_tiles = nullptr;
+    uint4 *d_fp_pack = nullptr;
     float *d_table = nullptr;
     float *d_tab_xs = nullptr, *d_tab_ys = nullptr, *d_tab_ts = nullptr;
     double *d_seg = nullptr;

@@ -380,13 +380,14 @@ static void set_resolution(DevMap &m, double res, double ox, double oy)
 static void free_map(hyas_ctx *c)
 {
     void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
-                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx};
+                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
     c->d_charmap = nullptr, c->d_quads = nullptr, c->d_cell_off = nullptr, c->d_cell_idx = nullptr, c->d_fp = nullptr;
     c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
     c->d_pose_off = c->d_seg_off = nullptr, c->d_pose_idx = c->d_seg_idx = nullptr;
+    c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr;
     c->have_map = c->have_table = false;
 }
 
@@ -397,6 +398,54 @@ static int upload(hyas_ctx *c, T *&dst, const std::vector<T> &src, size_t min_el
     HYAS_HIP(c, hipMalloc((void **)&dst, n * sizeof(T)));
     if (!src.empty())
         HYAS_HIP(c, hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HYAS_OK;
+}
+
+// Derived forms of the grid and the footprint table for the batched footprint kernel (DevMap::occ_tiles, fp_pack).
+static int upload_footprint_forms(hyas_ctx *c)
+{
+    DevMap &m = c->dm;
+    const uint32_t w = c->w, h = c->h, tx = (w + 7) / 8, ty = (h + 7) / 8;
+    std::vector<uint64_t> tiles((size_t)tx * ty, 0);
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x)
+            if (c->charmap[(size_t)y * w + x] >= 250)
+                tiles[(size_t)(y >> 3) * tx + (x >> 3)] |= 1ull << (((y & 7) << 3) | (x & 7));
+    int rc = upload(c, c->d_occ_tiles, tiles);
+    if (rc != HYAS_OK)
+        return rc;
+    m.occ_tiles = c->d_occ_tiles, m.tiles_x = tx;
+    const size_t entries = c->fp.size() / 129;
+    std::vector<uint4> pack(entries);
+    bool fits = entries * sizeof(uint4) <= 150 * 1024; // the kernel keeps the whole table in LDS
+    for (size_t e = 0; e < entries && fits; ++e)
+    {
+        const int32_t *src = &c->fp[e * 129];
+        uint8_t b[16] = {0};
+        if (src[0] < 0 || src[0] > 7)
+            fits = false;
+        else
+        {
+            b[0] = (uint8_t)src[0];
+            for (int i = 0; i < src[0]; ++i)
+            {
+                const int dx = src[1 + 2 * i], dy = src[2 + 2 * i];
+                if (dx < -128 || dx > 127 || dy < -128 || dy > 127)
+                    fits = false;
+                b[1 + 2 * i] = (uint8_t)(int8_t)dx, b[2 + 2 * i] = (uint8_t)(int8_t)dy;
+            }
+        }
+        std::memcpy(&pack[e], b, 16);
+    }
+    m.fp_pack = nullptr, m.fp_entries = (uint32_t)entries, m.fp_max_len = 0;
+    for (size_t e = 0; e < entries; ++e)
+        m.fp_max_len = std::max(m.fp_max_len, c->fp[e * 129]);
+    if (fits && entries)
+    {
+        if ((rc = upload(c, c->d_fp_pack, pack)) != HYAS_OK)
+            return rc;
+        m.fp_pack = c->d_fp_pack;
+    }
     return HYAS_OK;
 }
 
@@ -725,6 +774,8 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
 
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
     m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx, m.fp = c->d_fp;
+    if ((rc = upload_footprint_forms(c)) != HYAS_OK)
+        return rc;
     m.pose_off = c->d_pose_off, m.pose_idx = c->d_pose_idx, m.seg_off = c->d_seg_off, m.seg_idx = c->d_seg_idx;
     m.table = c->d_table, m.table_size = c->table_size;
     m.table_miss = (c->P.curve_type == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
@@ -775,6 +826,8 @@ int hyas_set_grid(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h)
     if ((rc = upload(c, c->d_fp, c->fp)) != HYAS_OK)
         return rc;
     m.charmap = c->d_charmap, m.fp = c->d_fp;
+    if ((rc = upload_footprint_forms(c)) != HYAS_OK)
+        return rc;
     c->have_map = true, c->have_table = false;
     c->grid_only = true;
     return HYAS_OK;

@@ -96,6 +96,15 @@ struct DevMap
     float delta_heading; // (float)(2*M_PI/(float)headings)
     // footprint-list mode
     const int32_t *fp;   // entries x {len, pos[64][2]}
+    // the same data in the form the batched footprint kernel gathers from:
+    //  occ_tiles: one bit per cell (1: cost >= 250), 8x8 cells per 64-bit word, word (Y>>3)*tiles_x + (X>>3),
+    //             bit ((Y&7)<<3)|(X&7): 1/8 of the byte grid, so a 4096x4096 map stays in one L2
+    //  fp_pack:   16 bytes per list {len, (dx, dy) as int8 x 7}; null when a list is longer or an offset wider
+    const uint64_t *occ_tiles;
+    uint32_t tiles_x;
+    const uint4 *fp_pack;
+    uint32_t fp_entries;
+    int32_t fp_max_len;
     // motion set
     int32_t n_succ;
     float succ_steer[HYAS_MAX_SUCC];
@@ -577,6 +586,8 @@ HD bool traversable(const DevMap &m, const QuadSrc &quads, float x, float y, flo
 HD bool footprint_free(const DevMap &m, float x, float y, float t)
 {
     const int pr = m.pr;
+    if (!(x == x) || !(y == y) || !(t == t))
+        return false; // NaN: the reference's int conversions give INT_MIN, i.e. off the grid
     int X = (int)x, Y = (int)y;
     int iX = (int)((x - (long)x) * pr);
     iX = iX > 0 ? iX : 0;

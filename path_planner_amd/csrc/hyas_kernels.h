@@ -32,7 +32,7 @@ void launch_shot_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_go
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
                   int stats_mode, hipStream_t s);
-void launch_shot_path(const DevMap &m, const StepIn &node, const hyas_goal &goal, const double *seg_tab, uint32_t seg_cap, float *out,
-                      uint32_t out_cap, uint32_t *n_out, hipStream_t s);
+void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
+                      const uint32_t *offsets, float *out, uint32_t *n_out, hipStream_t s);
 
 } // namespace hyas

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include "hyas_dev.h"
+#include <algorithm>
+
 #include "hyas_kernels.h"
 #include "hyas_rs.h"
 
@@ -55,6 +57,87 @@ __global__ void __launch_bounds__(256) k_collision_footprint(DevMap m, const flo
             for (size_t i = i0; i < n; ++i)
                 out[i] = footprint_free(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]) ? 1 : 0;
         }
+    }
+}
+
+// Footprint-list mode over the bit-tile grid with the packed footprint table in
+// LDS (include/lookup.h:30-284 builds the lists; the test itself is the
+// upstream configurationTest: every listed cell must be on the grid and free).
+// Four poses per thread; the up to 16 tile words of a thread are requested
+// before the first is used, so the gathers overlap.
+template <int MAXC>
+__global__ void __launch_bounds__(1024) k_collision_footprint_tiles(DevMap m, const float *__restrict__ xyt, size_t n,
+                                                                    uint8_t *__restrict__ out)
+{
+    extern __shared__ uint4 s_fp[];
+    for (uint32_t i = threadIdx.x; i < m.fp_entries; i += blockDim.x)
+        s_fp[i] = m.fp_pack[i];
+    __syncthreads();
+    const int pr = m.pr;
+    const size_t groups = n / 4;
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x)
+    {
+        const float4 *p = reinterpret_cast<const float4 *>(xyt + 12 * g);
+        const float4 a = p[0], b = p[1], c = p[2];
+        const float px[4] = {a.x, a.w, b.z, c.y}, py[4] = {a.y, b.x, b.w, c.z}, pt[4] = {a.z, b.y, c.x, c.w};
+        uint64_t word[4][MAXC];
+        uint32_t bit[4][MAXC]; // bit index, 64: cell not listed, 65: off the grid or pose outside the table
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const float x = px[k], y = py[k];
+            // |x|, |y| < 2^31 (false for NaN): there (long)x == (int)x, so the fraction needs no 64-bit conversion.
+            // Anything else is off the grid for the reference as well (its int conversion yields INT_MIN).
+            const bool sane = hy_fabsf(x) < 2147483648.f && hy_fabsf(y) < 2147483648.f && pt[k] == pt[k];
+            const int X = (int)x, Y = (int)y;
+            int iX = (int)((x - (float)X) * pr);
+            iX = iX > 0 ? iX : 0;
+            int iY = (int)((y - (float)Y) * pr);
+            iY = iY > 0 ? iY : 0;
+            const int iT = (int)(pt[k] / m.delta_heading);
+            const bool in_table = sane && !(iT < 0 || iT >= m.headings || iX >= pr || iY >= pr);
+            uint4 e = make_uint4(0, 0, 0, 0);
+            if (in_table)
+                e = s_fp[(iY * pr + iX) * m.headings + iT];
+            const uint32_t ew[4] = {e.x, e.y, e.z, e.w};
+            const int len = in_table ? (int)(e.x & 0xff) : 0;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i)
+            {
+                const int o = 1 + 2 * i; // byte offset of (dx, dy)
+                const int dx = (int)(int8_t)((ew[o >> 2] >> ((o & 3) * 8)) & 0xff);
+                const int dy = (int)(int8_t)((ew[(o + 1) >> 2] >> (((o + 1) & 3) * 8)) & 0xff);
+                const int cX = X + dx, cY = Y + dy;
+                const bool listed = i < len;
+                const bool on = cX >= 0 && (uint32_t)cX < m.w && cY >= 0 && (uint32_t)cY < m.h;
+                word[k][i] = 0;
+                bit[k][i] = !in_table ? 65u : !listed ? 64u : !on ? 65u : (uint32_t)(((cY & 7) << 3) | (cX & 7));
+                if (listed && on)
+                    word[k][i] = m.occ_tiles[(size_t)(cY >> 3) * m.tiles_x + (cX >> 3)];
+            }
+        }
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            bool free_ = bit[k][0] != 65u || MAXC == 0;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i)
+            {
+                if (bit[k][i] == 65u)
+                    free_ = false;
+                else if (bit[k][i] < 64u && ((word[k][i] >> bit[k][i]) & 1ull))
+                    free_ = false;
+            }
+            v |= free_ ? 1u << (8 * k) : 0u;
+        }
+        *reinterpret_cast<uint32_t *>(out + 4 * g) = v;
+    }
+    // the last n % 4 poses
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+    {
+        const size_t i = (n & ~(size_t)3) + threadIdx.x;
+        out[i] = footprint_free(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]) ? 1 : 0;
     }
 }
 
@@ -651,14 +734,19 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
         expand_role<MODE == 2 ? 0 : MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n);
 }
 
-// Writes the accepted curve of one query: n samples {x, y, t} (+ the caller
-// appends the goal, :526).
-__global__ void __launch_bounds__(256) k_shot_path(DevMap m, StepIn node, hyas_goal goal,
+// The accepted curves of n queries, one workgroup each: samples {x, y, t} of
+// the shot from nodes[i] to goals[nodes[i].query] (the caller appends the goal,
+// src/hybrid_a_star.cpp:526).  With offsets == nullptr only the sample counts
+// are written; otherwise query i's samples start at out + 3 * offsets[i].
+__global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__restrict__ nodes, const hyas_goal *__restrict__ goals,
                                                    const double *__restrict__ seg_tab, uint32_t seg_cap,
-                                                   float *__restrict__ out, uint32_t out_cap, uint32_t *n_out)
+                                                   const uint32_t *__restrict__ offsets, float *__restrict__ out,
+                                                   uint32_t *__restrict__ n_out)
 {
     __shared__ rs::Path s_path;
     const int tid = threadIdx.x;
+    const StepIn node = nodes[blockIdx.x];
+    const hyas_goal goal = goals[node.query];
     const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
     const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
     const double rho = (double)m.shot_rho;
@@ -674,13 +762,18 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, StepIn node, hyas_g
     const rs::Path path = s_path;
     const double length = rho * path.total;
     const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
-    if (tid == 0)
-        *n_out = nsamp;
-    for (uint32_t k = tid; k < nsamp && k < out_cap; k += blockDim.x)
+    if (!offsets)
+    {
+        if (tid == 0)
+            n_out[blockIdx.x] = nsamp;
+        return;
+    }
+    float *dst = out + 3 * (size_t)offsets[blockIdx.x];
+    for (uint32_t k = tid; k < nsamp; k += blockDim.x)
     {
         double s[3];
         rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
-        out[3 * k] = (float)s[0], out[3 * k + 1] = (float)s[1], out[3 * k + 2] = rad_0_2pi((float)s[2]);
+        dst[3 * k] = (float)s[0], dst[3 * k + 1] = (float)s[1], dst[3 * k + 2] = rad_0_2pi((float)s[2]);
     }
 }
 
@@ -697,7 +790,23 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
 {
     if (n == 0)
         return;
-    if (mode == HYAS_MODE_FOOTPRINT)
+    if (mode == HYAS_MODE_FOOTPRINT && m.fp_pack && m.occ_tiles)
+    {
+        // one workgroup per CU (the table takes most of its LDS), grid-stride over the poses
+        const size_t lds = (size_t)m.fp_entries * sizeof(uint4);
+        const int blocks = (int)std::min<size_t>(256, (n / 4 + 1023) / 1024 + 1);
+        if (m.fp_max_len <= 4)
+        {
+            (void)hipFuncSetAttribute((const void *)k_collision_footprint_tiles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_collision_footprint_tiles<4>, dim3(blocks), dim3(1024), lds, s, m, xyt, n, out);
+        }
+        else
+        {
+            (void)hipFuncSetAttribute((const void *)k_collision_footprint_tiles<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_collision_footprint_tiles<7>, dim3(blocks), dim3(1024), lds, s, m, xyt, n, out);
+        }
+    }
+    else if (mode == HYAS_MODE_FOOTPRINT)
         hipLaunchKernelGGL(k_collision_footprint, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, m, xyt, n, out);
     else
         hipLaunchKernelGGL(k_collision_polygon, dim3(grid_for(n)), dim3(256), 0, s, m, xyt, pred_xy, n, out);
@@ -781,10 +890,12 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
         hipLaunchKernelGGL(k_round<0>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
 }
 
-void launch_shot_path(const DevMap &m, const StepIn &node, const hyas_goal &goal, const double *seg_tab, uint32_t seg_cap, float *out,
-                      uint32_t out_cap, uint32_t *n_out, hipStream_t s)
+void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
+                      const uint32_t *offsets, float *out, uint32_t *n_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_shot_path, dim3(1), dim3(256), 0, s, m, node, goal, seg_tab, seg_cap, out, out_cap, n_out);
+    if (!n)
+        return;
+    hipLaunchKernelGGL(k_shot_path, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
 }
 
 } // namespace hyas

@@ -707,34 +707,61 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
 
         if (std::getenv("HYAS_TRACE"))
             fprintf(stderr, "hyas rounds (%d groups): host push+pop %.3f s, launch %.3f s, wait %.3f s\n", ng, t_host, t_launch, t_wait);
-        // queries closed by an analytic shot: fetch the curve samples
-        // (:160-172: TracePath + the sampled curve + the goal)
-        for (size_t i = 0; i < cn; ++i)
+        // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
+        // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
-            Query &q = Q[i];
-            if (q.shot_from < 0)
-                continue;
-            const SNode &nd = q.arena[q.shot_from];
-            const uint32_t cap = c->seg_cap;
-            rc = ensure_scratch(c, std::max<size_t>(off, (size_t)cap * 3 * sizeof(float) + 256), 0);
-            if (rc != HYAS_OK)
-                return rc;
-            ds = (char *)c->d_scratch;
-            float *d_pts = (float *)ds;
-            uint32_t *d_n = (uint32_t *)(ds + (size_t)cap * 3 * sizeof(float));
-            StepIn in{nd.x, nd.y, nd.t, nd.g, nd.prim, (uint32_t)i, 1, 0};
-            launch_shot_path(m, in, q.goal, c->d_seg, c->seg_cap, d_pts, cap, d_n, c->stream);
-            uint32_t npts = 0;
-            HYAS_HIP(c, hipMemcpyAsync(&npts, d_n, sizeof npts, hipMemcpyDeviceToHost, c->stream));
-            HYAS_HIP(c, hipStreamSynchronize(c->stream));
-            npts = std::min(npts, cap);
-            shot_buf.resize((size_t)npts * 3);
-            if (npts)
-                HYAS_HIP(c, hipMemcpy(shot_buf.data(), d_pts, (size_t)npts * 3 * sizeof(float), hipMemcpyDeviceToHost));
-            D.trace(q, q.shot_from, q.path);
-            q.path.insert(q.path.end(), shot_buf.begin(), shot_buf.end());
-            q.path.push_back(q.goal.x), q.path.push_back(q.goal.y), q.path.push_back(q.goal.t);
-            D.finish(q, HYAS_STATUS_SHOT, q.shot_from);
+            std::vector<uint32_t> shot_q;
+            for (size_t i = 0; i < cn; ++i)
+                if (Q[i].shot_from >= 0)
+                    shot_q.push_back((uint32_t)i);
+            const size_t nsq = shot_q.size();
+            if (nsq)
+            {
+                // the round staging is idle now: nodes reuse the StepIn slots, counts and offsets the result slices
+                uint32_t *h_cnt = (uint32_t *)(hs + o_succ), *h_off = h_cnt + nsq;
+                uint32_t *d_cnt = (uint32_t *)(ds + o_succ), *d_off = d_cnt + nsq;
+                for (size_t k = 0; k < nsq; ++k)
+                {
+                    const Query &q = Q[shot_q[k]];
+                    const SNode &nd = q.arena[q.shot_from];
+                    h_in[k] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, shot_q[k], 1, 0};
+                }
+                HYAS_HIP(c, hipMemcpyAsync(ds + o_in, h_in, nsq * sizeof(StepIn), hipMemcpyHostToDevice, c->stream));
+                launch_shot_path(m, (const StepIn *)(ds + o_in), (uint32_t)nsq, (const hyas_goal *)(ds + o_goal), c->d_seg, c->seg_cap, nullptr,
+                                 nullptr, d_cnt, c->stream);
+                HYAS_HIP(c, hipMemcpyAsync(h_cnt, d_cnt, nsq * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                HYAS_HIP(c, hipStreamSynchronize(c->stream));
+                size_t total = 0;
+                for (size_t k = 0; k < nsq; ++k)
+                    h_off[k] = (uint32_t)total, total += h_cnt[k];
+                float *d_pts = nullptr;
+                HYAS_HIP(c, hipMalloc((void **)&d_pts, std::max<size_t>(total, 1) * 3 * sizeof(float)));
+                shot_buf.resize(total * 3);
+                hipError_t e = hipMemcpyAsync(d_off, h_off, nsq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess)
+                {
+                    launch_shot_path(m, (const StepIn *)(ds + o_in), (uint32_t)nsq, (const hyas_goal *)(ds + o_goal), c->d_seg, c->seg_cap,
+                                     d_off, d_pts, nullptr, c->stream);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess && total)
+                    e = hipMemcpyAsync(shot_buf.data(), d_pts, total * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(c->stream);
+                (void)hipFree(d_pts);
+                if (e != hipSuccess)
+                    return hip_fail(c, e, "shot path download");
+                pool.run(nsq, [&](size_t a, size_t b) {
+                    for (size_t k = a; k < b; ++k)
+                    {
+                        Query &q = Q[shot_q[k]];
+                        D.trace(q, q.shot_from, q.path);
+                        q.path.insert(q.path.end(), shot_buf.begin() + 3 * (size_t)h_off[k], shot_buf.begin() + 3 * ((size_t)h_off[k] + h_cnt[k]));
+                        q.path.push_back(q.goal.x), q.path.push_back(q.goal.y), q.path.push_back(q.goal.t);
+                        D.finish(q, HYAS_STATUS_SHOT, q.shot_from);
+                    }
+                });
+            }
         }
 
         for (size_t i = 0; i < cn; ++i)

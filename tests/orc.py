@@ -122,7 +122,7 @@ class Oracle:
                   "orc_table_lookup", "orc_plan", "orc_get_path", "orc_get_expanded", "orc_footprint_table",
                   "orc_get_obstacles", "orc_in_range_count", "orc_num_obstacles", "orc_num_successors",
                   "orc_table_dims", "orc_build_table", "orc_rs_path", "orc_rs_sample", "orc_dubins",
-                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size"):
+                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid"):
             getattr(L, f).argtypes = None
         self.params = params
         self.h = C.c_void_p(L.orc_create(C.byref(params)))
@@ -140,6 +140,11 @@ class Oracle:
         nthreads = nthreads or min(8, os.cpu_count() or 1)
         self.L.orc_set_costmap(self.h, cm.ctypes.data_as(C.c_void_p), C.c_uint32(self.w), C.c_uint32(self.hgt),
                                C.c_double(res), C.c_double(ox), C.c_double(oy), int(build_table), int(nthreads))
+
+    def set_grid(self, charmap):
+        charmap = np.ascontiguousarray(charmap, np.uint8)
+        self.hgt, self.w = charmap.shape
+        self.L.orc_set_grid(self.h, charmap.ctypes.data_as(C.c_void_p), C.c_uint32(self.w), C.c_uint32(self.hgt))
 
     def obstacles(self):
         n = self.L.orc_num_obstacles(self.h)

@@ -245,3 +245,37 @@ def test_plan_golden_fixture():
             assert h.path(i).tobytes() == g[f"{n}/path"].tobytes(), n
             # path cost within 1e-6 relative is implied by the bitwise match; stated for the record
             assert abs(float(res[i]["g_final"]) - float(g[f"{n}/result"]["g_final"])) <= 1e-6 * max(1.0, float(res[i]["g_final"]))
+
+
+@pytest.mark.parametrize("fp", [(0.18, 0.22), (1.2, 1.7), (2.0, 4.5)], ids=["in_tree", "mid", "car"])
+def test_footprint_grid_only(fp, oracle_built):
+    """hyas_set_grid + footprint-list test on a random grid whose size is not a multiple of the 8x8 bit tiles:
+    short lists (packed table in LDS), lists of 5..7 cells, and long lists (general table walk)."""
+    W, H = 1501, 1099
+    grid = np.where(np.random.default_rng(1).random((H, W)) < 0.10, 254, 0).astype(np.uint8)
+    grid[np.random.default_rng(2).random((H, W)) < 0.02] = 250  # the threshold value itself
+    grid[np.random.default_rng(3).random((H, W)) < 0.02] = 249
+    po, ph = _params(fp_width=fp[0], fp_length=fp[1])
+    po.position_resolution = ph.position_resolution = 10
+    o = orc.Oracle(po)
+    o.set_grid(grid)
+    h = Hyas(ph)
+    h.set_grid(grid)
+    ta, tb = o.footprint_table(), h.footprint_table()
+    assert np.array_equal(ta, tb)
+    rng = np.random.default_rng(4)
+    n = 400003
+    xyt = np.stack([rng.uniform(-3, W + 3, n), rng.uniform(-3, H + 3, n), rng.uniform(-0.5, 6.6, n)], 1).astype(np.float32)
+    xyt[:1000, 0] = np.round(xyt[:1000, 0])  # cell borders
+    xyt[1000:2000, 1] = np.round(xyt[1000:2000, 1])
+    # values the int conversions cannot represent: off the grid for both sides
+    xyt[2000:2008, 0] = [np.nan, 1e10, -1e10, 3e9, -3e9, np.inf, -np.inf, 2147483648.0]
+    xyt[2008:2016, 1] = [np.nan, 1e10, -1e10, 3e9, -3e9, np.inf, -np.inf, 2147483648.0]
+    xyt[2016:2020, 2] = [np.nan, 1e10, -1e10, np.inf]
+    a = o.collision(xyt, mode=1)
+    b = h.collision(xyt, mode=hl.MODE_FOOTPRINT)
+    assert np.array_equal(a, b), int((a != b).sum())
+    assert 0.05 < a.mean() < 0.95
+    assert not a[2000:2020].any()
+    if fp == (0.18, 0.22):
+        assert int(ta[:, 0].max()) == 4
