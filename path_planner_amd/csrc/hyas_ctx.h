@@ -47,6 +47,7 @@ struct hyas_ctx
     float *d_table = nullptr;
     float *d_tab_xs = nullptr, *d_tab_ys = nullptr, *d_tab_ts = nullptr;
     double *d_seg = nullptr;
+    float *d_seg_db = nullptr;
     uint32_t *d_pose_off = nullptr, *d_seg_off = nullptr;
     uint16_t *d_pose_idx = nullptr, *d_seg_idx = nullptr;
     size_t n_pose_entries = 0, n_seg_entries = 0;

@@ -380,14 +380,14 @@ static void set_resolution(DevMap &m, double res, double ox, double oy)
 static void free_map(hyas_ctx *c)
 {
     void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
-                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack};
+                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack, c->d_seg_db};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
     c->d_charmap = nullptr, c->d_quads = nullptr, c->d_cell_off = nullptr, c->d_cell_idx = nullptr, c->d_fp = nullptr;
     c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
     c->d_pose_off = c->d_seg_off = nullptr, c->d_pose_idx = c->d_seg_idx = nullptr;
-    c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr;
+    c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr, c->d_seg_db = nullptr;
     c->have_map = c->have_table = false;
 }
 
@@ -603,14 +603,18 @@ int hyas_table_build_dev(hyas_ctx *c, int curve, int k0, int k1, float *out_dev)
 {
     if (!c || !c->have_map)
         return HYAS_ESTATE;
-    if (curve != HYAS_CURVE_RS)
-        return c->fail(HYAS_EINVAL, "only the Reeds-Shepp table is built on the GPU");
+    if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
+        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
     if (k0 < 0 || k1 > (int)c->tab_ts.size() || k0 > k1 || !out_dev)
         return c->fail(HYAS_EINVAL, "slice range outside the heading loop");
     HYAS_HIP(c, hipSetDevice(c->device));
     timer_begin(c);
-    launch_table_rs(c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts, (uint32_t)k0,
-                    (uint32_t)k1, (double)c->P.cd_min_turning_radius, out_dev, c->stream);
+    if (curve == HYAS_CURVE_RS)
+        launch_table_rs(c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts, (uint32_t)k0,
+                        (uint32_t)k1, (double)c->P.cd_min_turning_radius, out_dev, c->stream);
+    else
+        launch_table_dubins(c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts, (uint32_t)k0,
+                            (uint32_t)k1, c->P.cd_min_turning_radius, out_dev, c->stream);
     HYAS_HIP(c, hipGetLastError());
     HYAS_HIP(c, hipStreamSynchronize(c->stream));
     timer_end(c, 3);
@@ -770,6 +774,19 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
         c->seg_cap = (uint32_t)cap;
         if ((rc = upload(c, c->d_seg, seg)) != HYAS_OK)
             return rc;
+        // Dubins shot: x after k additions of 0.2*resolution, float with the sum formed in double
+        // (src/hybrid_a_star.cpp:396-424)
+        const size_t cap_db = cap / 2 + 16;
+        std::vector<float> seg_db(cap_db);
+        float x = 0.f;
+        for (size_t k = 0; k < cap_db; ++k)
+        {
+            seg_db[k] = x;
+            x = (float)((double)x + 0.2 * (double)m.res_f);
+        }
+        if ((rc = upload(c, c->d_seg_db, seg_db)) != HYAS_OK)
+            return rc;
+        m.seg_db = c->d_seg_db, m.seg_db_cap = (uint32_t)cap_db;
     }
 
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
@@ -783,14 +800,12 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
 
     if (build_table)
     {
-        if (c->P.curve_type != HYAS_CURVE_RS)
-            return c->fail(HYAS_EINVAL, "Dubins heuristic table is not built on the GPU yet");
         const size_t total = c->tab_xs.size() * c->tab_ys.size() * c->tab_ts.size();
         float *raw = nullptr;
         HYAS_HIP(c, hipMalloc((void **)&raw, std::max<size_t>(total, 1) * sizeof(float)));
-        rc = hyas_table_build_dev(c, HYAS_CURVE_RS, 0, (int)c->tab_ts.size(), raw);
+        rc = hyas_table_build_dev(c, c->P.curve_type, 0, (int)c->tab_ts.size(), raw);
         if (rc == HYAS_OK)
-            rc = hyas_table_install_dev(c, HYAS_CURVE_RS, raw);
+            rc = hyas_table_install_dev(c, c->P.curve_type, raw);
         (void)hipFree(raw);
         if (rc != HYAS_OK)
             return rc;
@@ -931,8 +946,6 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
 {
     if (!c || !c->have_map || !c->have_table)
         return HYAS_ESTATE;
-    if (c->P.curve_type != HYAS_CURVE_RS)
-        return c->fail(HYAS_EINVAL, "the expansion step implements the Reeds-Shepp configuration (curve_type 1)");
     if (n == 0)
         return HYAS_OK;
     if (n > 0x7fffffffu)
@@ -959,7 +972,7 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
     HYAS_HIP(c, hipMemsetAsync(ds + o_succ, 0, off - o_succ, c->stream));
     timer_begin(c);
     if (shoot)
-        launch_shot_rs(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), c->d_seg, c->seg_cap,
+        launch_shot(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), c->d_seg, c->seg_cap,
                        (uint8_t *)(ds + o_ok), (float *)(ds + o_len), nullptr, 0, c->stream);
     else
         launch_expand(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), twod ? c->d_twod : nullptr,
@@ -1000,8 +1013,6 @@ int hyas_plan_batch(hyas_ctx *c, const float *starts, const float *goals, size_t
         return HYAS_ESTATE;
     if (n && (!starts || !goals || !out))
         return c->fail(HYAS_EINVAL, "null buffer");
-    if (c->P.curve_type != HYAS_CURVE_RS)
-        return c->fail(HYAS_EINVAL, "plan_batch implements the Reeds-Shepp configuration (curve_type 1)");
     return plan_batch_impl(c, starts, goals, n, out);
 }
 

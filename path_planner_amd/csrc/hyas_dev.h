@@ -113,6 +113,9 @@ struct DevMap
     float shot_rho; // params.min_turning_radius
     int32_t curve_type;
     uint32_t twod_size; // floats per 2D cost map: w*h + w + 1
+    // Dubins shot: sample positions x_k of `x += 0.2 * res` in float (src/hybrid_a_star.cpp:396-424)
+    const float *seg_db;
+    uint32_t seg_db_cap;
 };
 
 // ---------------------------------------------------------------- Utility::

@@ -22,12 +22,14 @@ void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint3
                      uint8_t *flags, hipStream_t s);
 void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,
                      float *out, hipStream_t s);
+void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,
+                         float *out, hipStream_t s);
 void launch_table_install(const DevMap &m, const float *raw, const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts,
                           uint32_t ns, uint32_t *rank, float *table, uint64_t table_size, hipStream_t s);
 void launch_table_lookup(const DevMap &m, const float *xyt, size_t n, float *cost, hipStream_t s);
 void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, uint8_t *count,
                    hyas_succ *succ, unsigned long long *stats, int stats_mode, hipStream_t s);
-void launch_shot_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
+void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                     uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s);
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,

@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "hyas_kernels.h"
+#include "hyas_dubins.h"
 #include "hyas_rs.h"
 
 namespace hyas
@@ -181,6 +182,25 @@ __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, 
     }
 }
 
+// The same for curve_type 0 (src/lookup_table.cpp:147-180).  OMPL's DubinsStateSpace is not part of the
+// reference tree; the in-tree float solver (src/dubins.cpp) stands in, 1e6 where no word connects.
+__global__ void __launch_bounds__(256) k_table_dubins(const float *__restrict__ xs, uint32_t nx,
+                                                      const float *__restrict__ ys, uint32_t ny,
+                                                      const float *__restrict__ ts, uint32_t k0, uint32_t k1, float rho,
+                                                      float *__restrict__ out)
+{
+    const size_t total = (size_t)(k1 - k0) * ny * nx;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    {
+        uint32_t i = (uint32_t)(e % nx);
+        uint32_t j = (uint32_t)((e / nx) % ny);
+        uint32_t k = k0 + (uint32_t)(e / ((size_t)nx * ny));
+        const float a[3] = {0, 0, 0}, b[3] = {xs[i], ys[j], ts[k]};
+        db::Path p;
+        out[e] = (db::init(a, b, rho, p) != 0) ? 1000000.f : db::length(p);
+    }
+}
+
 // First-write-wins emplace (src/lookup_table.cpp:215) in two passes: pass 0
 // records for every key the earliest loop position (x outer, y, theta inner)
 // that maps to it, pass 1 lets exactly that position store its cost.
@@ -273,6 +293,22 @@ __device__ __forceinline__ uint32_t count_samples(const double *__restrict__ seg
     {
         uint32_t mid = (lo + hi) >> 1;
         if (seg_tab[mid] <= length)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// Number of samples of the Dubins shot loop `x = 0; while (x < length) x += 0.2 * res`
+// (src/hybrid_a_star.cpp:396-424): seg_tab[k] holds x after k additions.
+__device__ __forceinline__ uint32_t count_samples_db(const float *__restrict__ seg_tab, uint32_t cap, float length)
+{
+    uint32_t lo = 0, hi = cap; // first k with !(seg_tab[k] < length)
+    while (lo < hi)
+    {
+        uint32_t mid = (lo + hi) >> 1;
+        if (seg_tab[mid] < length)
             lo = mid + 1;
         else
             hi = mid;
@@ -502,7 +538,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
 // colliding one (what a serial scan tests), 2 obstacle-list entries behind (1),
 // 7 shots; (MODE 2) shader-clock sums: 8 phases 1+2, 9 interpolation,
 // 10 collision tests, 11..14 phase 1 per wave, 6 workgroups, 19 sample batches.
-template <int MODE>
+template <int MODE, int CURVE>
 __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restrict__ in, const hyas_goal *__restrict__ goals,
                                           const double *__restrict__ seg_tab, uint32_t seg_cap, uint8_t *__restrict__ shot_ok,
                                           float *__restrict__ shot_len, unsigned long long *stats, Quad *s_quads, uint32_t slot)
@@ -510,9 +546,11 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     __shared__ CandOut s_cand[RS_NUM_CANDIDATES];
     __shared__ rs::Path s_path;
     __shared__ rs::Prefix s_prefix;
+    __shared__ db::Path s_dubins;
     __shared__ float s_xyt[SHOT_THREADS + 1][3]; // [0] = the sample in front of this batch
     __shared__ int s_hit;
     __shared__ unsigned int s_first, s_lists;
+    constexpr bool RS = CURVE == HYAS_CURVE_RS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StepIn node = in[slot];
     if (node.shoot == 0) // uniform across the workgroup
@@ -530,6 +568,22 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     const StepQuads sq = stage_quads(m, s_quads, tid); // visible after the barrier that ends phase 1
 
     // ---- phase 1 ------------------------------------------------------------
+    if (!RS)
+    {
+        // Dubins: six float words, cheap next to the sample tests; one lane solves (src/hybrid_a_star.cpp:378-395)
+        if (tid == 0)
+        {
+            const float a[3] = {node.x, node.y, node.t}, b[3] = {goal.x, goal.y, goal.t};
+            db::Path p;
+            p.qi[0] = a[0], p.qi[1] = a[1], p.qi[2] = a[2];
+            p.param[0] = p.param[1] = p.param[2] = 0, p.type = 0, p.rho = m.shot_rho;
+            (void)db::init(a, b, m.shot_rho, p);
+            s_dubins = p;
+            s_hit = 0;
+            s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t;
+        }
+    }
+    else
     {
         // candidate groups per wave (group = closed form x backwards?, four symmetries each)
         const int groups[4][3] = {{0, 1, 10}, {2, 3, 9}, {4, 5, -1}, {6, 8, 7}};
@@ -557,7 +611,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     __syncthreads();
 
     // ---- phase 2 ------------------------------------------------------------
-    if (wave == 0)
+    if (RS && wave == 0)
     {
         rs::Path mine = rs::empty_path();
         double L = 0;
@@ -588,10 +642,24 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     }
 
     // ---- phase 3 ------------------------------------------------------------
-    const rs::Path path = s_path;
+    rs::Path path;
+    db::Path dpath;
     const double rho = (double)m.shot_rho;
-    const double length = rho * path.total; // src/ReedsShepp.cpp:564
-    const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
+    double length;
+    uint32_t nsamp;
+    if (RS)
+    {
+        path = s_path;
+        length = rho * path.total; // src/ReedsShepp.cpp:564
+        nsamp = count_samples(seg_tab, seg_cap, length);
+    }
+    else
+    {
+        dpath = s_dubins;
+        const float lf = db::length(dpath);
+        length = (double)lf;
+        nsamp = count_samples_db(m.seg_db, m.seg_db_cap, lf);
+    }
     bool collided = false;
     unsigned long long tested = 0;
     for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_THREADS)
@@ -607,9 +675,18 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             float x = 0, y = 0, t = 0;
             if (k < nsamp)
             {
-                double s[3];
-                rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
-                x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+                if (RS)
+                {
+                    double s[3];
+                    rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
+                    x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+                }
+                else
+                {
+                    float q[3] = {0, 0, 0};
+                    (void)db::sample(dpath, m.seg_db[k], q);
+                    x = q[0], y = q[1], t = rad_0_2pi(q[2]);
+                }
             }
             if (base)
                 __syncthreads(); // slot 0 has been refreshed before slot SHOT_THREADS is overwritten
@@ -703,23 +780,23 @@ __global__ void __launch_bounds__(ROUND_THREADS) k_expand(DevMap m, const StepIn
     expand_role<MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_shot_rs(DevMap m, const StepIn *__restrict__ in, uint32_t n,
-                                                                          const hyas_goal *__restrict__ goals,
-                                                                          const double *__restrict__ seg_tab, uint32_t seg_cap,
-                                                                          uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
-                                                                          unsigned long long *stats)
+template <int MODE, int CURVE>
+__global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_shot(DevMap m, const StepIn *__restrict__ in, uint32_t n,
+                                                                       const hyas_goal *__restrict__ goals,
+                                                                       const double *__restrict__ seg_tab, uint32_t seg_cap,
+                                                                       uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
+                                                                       unsigned long long *stats)
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
     if (blockIdx.x < n)
-        shot_role<MODE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
+        shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
 }
 
 // One search round in one launch: workgroups [0, n) evaluate the analytic shot
 // of node i, the following ceil(n / 16) workgroups the successors of 16 nodes
 // each.  The two parts are independent; the shot workgroups come first because
 // they run longest.
-template <int MODE>
+template <int MODE, int CURVE>
 __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap m, const StepIn *__restrict__ in, uint32_t n,
                                                                         const hyas_goal *__restrict__ goals, const float *__restrict__ twod,
                                                                         const double *__restrict__ seg_tab, uint32_t seg_cap,
@@ -729,7 +806,7 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
     if (blockIdx.x < n) // uniform across the workgroup
-        shot_role<MODE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
+        shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
     else
         expand_role<MODE == 2 ? 0 : MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n);
 }
@@ -738,30 +815,48 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
 // the shot from nodes[i] to goals[nodes[i].query] (the caller appends the goal,
 // src/hybrid_a_star.cpp:526).  With offsets == nullptr only the sample counts
 // are written; otherwise query i's samples start at out + 3 * offsets[i].
+template <int CURVE>
 __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__restrict__ nodes, const hyas_goal *__restrict__ goals,
                                                    const double *__restrict__ seg_tab, uint32_t seg_cap,
                                                    const uint32_t *__restrict__ offsets, float *__restrict__ out,
                                                    uint32_t *__restrict__ n_out)
 {
     __shared__ rs::Path s_path;
+    __shared__ db::Path s_dubins;
     const int tid = threadIdx.x;
     const StepIn node = nodes[blockIdx.x];
     const hyas_goal goal = goals[node.query];
     const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
     const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
     const double rho = (double)m.shot_rho;
-    if (tid < 64)
+    if (CURVE == HYAS_CURVE_RS)
     {
-        double x, y, phi;
-        rs::normalise(q0, q1, rho, x, y, phi);
-        rs::Path p = solve_wave(x, y, phi, tid);
-        if (tid == 0)
-            s_path = p;
+        if (tid < 64)
+        {
+            double x, y, phi;
+            rs::normalise(q0, q1, rho, x, y, phi);
+            rs::Path p = solve_wave(x, y, phi, tid);
+            if (tid == 0)
+                s_path = p;
+        }
+    }
+    else if (tid == 0)
+    {
+        const float a[3] = {node.x, node.y, node.t}, b[3] = {goal.x, goal.y, goal.t};
+        db::Path p;
+        p.qi[0] = a[0], p.qi[1] = a[1], p.qi[2] = a[2];
+        p.param[0] = p.param[1] = p.param[2] = 0, p.type = 0, p.rho = m.shot_rho;
+        (void)db::init(a, b, m.shot_rho, p);
+        s_dubins = p;
     }
     __syncthreads();
     const rs::Path path = s_path;
-    const double length = rho * path.total;
-    const uint32_t nsamp = count_samples(seg_tab, seg_cap, length);
+    const db::Path dpath = s_dubins;
+    uint32_t nsamp;
+    if (CURVE == HYAS_CURVE_RS)
+        nsamp = count_samples(seg_tab, seg_cap, rho * path.total);
+    else
+        nsamp = count_samples_db(m.seg_db, m.seg_db_cap, db::length(dpath));
     if (!offsets)
     {
         if (tid == 0)
@@ -771,9 +866,18 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
     float *dst = out + 3 * (size_t)offsets[blockIdx.x];
     for (uint32_t k = tid; k < nsamp; k += blockDim.x)
     {
-        double s[3];
-        rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
-        dst[3 * k] = (float)s[0], dst[3 * k + 1] = (float)s[1], dst[3 * k + 2] = rad_0_2pi((float)s[2]);
+        if (CURVE == HYAS_CURVE_RS)
+        {
+            double s[3];
+            rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
+            dst[3 * k] = (float)s[0], dst[3 * k + 1] = (float)s[1], dst[3 * k + 2] = rad_0_2pi((float)s[2]);
+        }
+        else
+        {
+            float q[3] = {0, 0, 0};
+            (void)db::sample(dpath, m.seg_db[k], q);
+            dst[3 * k] = q[0], dst[3 * k + 1] = q[1], dst[3 * k + 2] = rad_0_2pi(q[2]);
+        }
     }
 }
 
@@ -830,6 +934,15 @@ void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny,
     hipLaunchKernelGGL(k_table_rs, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
 }
 
+void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,
+                         float *out, hipStream_t s)
+{
+    size_t total = (size_t)(k1 - k0) * ny * nx;
+    if (total == 0)
+        return;
+    hipLaunchKernelGGL(k_table_dubins, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
+}
+
 void launch_table_install(const DevMap &m, const float *raw, const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts,
                           uint32_t ns, uint32_t *rank, float *table, uint64_t table_size, hipStream_t s)
 {
@@ -862,17 +975,30 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
         hipLaunchKernelGGL(k_expand<0>, grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
 }
 
-void launch_shot_rs(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
-                    uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s)
+// kernel<MODE, CURVE> chosen at run time
+#define HYAS_DISPATCH(KERNEL, grid, block, stream, ...)                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const int mode_ = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;                              \
+        const bool rs_ = m.curve_type == HYAS_CURVE_RS;                                                                \
+        if (mode_ == 0 && rs_)                                                                                         \
+            hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
+        else if (mode_ == 1 && rs_)                                                                                    \
+            hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
+        else if (mode_ == 2 && rs_)                                                                                    \
+            hipLaunchKernelGGL((KERNEL<2, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
+        else if (mode_ == 1)                                                                                           \
+            hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_DUBINS>), grid, block, 0, stream, __VA_ARGS__);                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_DUBINS>), grid, block, 0, stream, __VA_ARGS__);                   \
+    } while (0)
+
+void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
+                 uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s)
 {
     if (!n)
         return;
-    if (stats && stats_mode == 2)
-        hipLaunchKernelGGL(k_shot_rs<2>, dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
-    else if (stats && stats_mode == 1)
-        hipLaunchKernelGGL(k_shot_rs<1>, dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
-    else
-        hipLaunchKernelGGL(k_shot_rs<0>, dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
+    HYAS_DISPATCH(k_shot, dim3(n), dim3(SHOT_THREADS), s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
 }
 
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
@@ -882,12 +1008,7 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
     if (!n)
         return;
     const dim3 grid(n + (n + ROUND_THREADS / 16 - 1) / (ROUND_THREADS / 16));
-    if (stats && stats_mode == 2)
-        hipLaunchKernelGGL(k_round<2>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
-    else if (stats && stats_mode == 1)
-        hipLaunchKernelGGL(k_round<1>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
-    else
-        hipLaunchKernelGGL(k_round<0>, grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
+    HYAS_DISPATCH(k_round, grid, dim3(ROUND_THREADS), s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
 }
 
 void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
@@ -895,7 +1016,10 @@ void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hy
 {
     if (!n)
         return;
-    hipLaunchKernelGGL(k_shot_path, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
+    if (m.curve_type == HYAS_CURVE_RS)
+        hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_RS>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
+    else
+        hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_DUBINS>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
 }
 
 } // namespace hyas

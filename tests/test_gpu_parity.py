@@ -279,3 +279,65 @@ def test_footprint_grid_only(fp, oracle_built):
     assert not a[2000:2020].any()
     if fp == (0.18, 0.22):
         assert int(ta[:, 0].max()) == 4
+
+
+# ----------------------------------------------------------------- Dubins (curve_type 0)
+@pytest.fixture(scope="module")
+def parking_dubins(oracle_built):
+    # turning radius small enough that shots connect inside the 60x30 map
+    return Pair("map_parking", position_resolution=2, curve_type=0, min_turning_radius=2.0, cd_min_turning_radius=2.0,
+                max_iterations=400)
+
+
+@pytest.fixture(scope="module")
+def maze_dubins_default(oracle_built):
+    # the reference's struct defaults: Dubins, three forward successors, no reverse, radius 6
+    po = orc.default_params(position_resolution=2, max_iterations=200)
+    ph = Params()
+    for name, _ in Params._fields_:
+        setattr(ph, name, getattr(po, name))
+    p = Pair.__new__(Pair)
+    p.map = orc.load_map("map_maze")
+    p.o = orc.Oracle(po)
+    p.o.set_costmap(p.map, build_table=True, nthreads=16)
+    p.h = Hyas(ph)
+    p.h.set_costmap(p.map, build_table=True)
+    p.H, p.W = p.map.shape
+    p.res, p.ox, p.oy = 1.0, 0.0, 0.0
+    return p
+
+
+def test_dubins_table(parking_dubins):
+    p = parking_dubins
+    nx, ny, ns = p.h.table_dims()
+    assert (nx, ny, ns) == p.o.table_dims()
+    rng = np.random.default_rng(5)
+    q = np.stack([rng.uniform(0, p.W, 100000), rng.uniform(0, p.H, 100000), rng.uniform(-7, 7, 100000)], 1).astype(np.float32)
+    assert np.array_equal(p.o.table_lookup(q).view(np.uint32), p.h.table_lookup(q).view(np.uint32))
+    gx, gy = np.meshgrid(np.arange(nx) * 0.5, np.arange(ny) * 0.5, indexing="ij")
+    for t in (0.0, 1.0, 3.1, 6.2):
+        g = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, t)], 1).astype(np.float32)
+        a, b = p.o.table_lookup(g), p.h.table_lookup(g)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert (a < 1e6).mean() > 0.9
+
+
+def test_dubins_shot_and_expand(parking_dubins, maze_dubins_default):
+    for p, seed in ((parking_dubins, 81), (maze_dubins_default, 82)):
+        nodes, goals = _nodes(p, 1500, seed)
+        a, la = p.o.shot(nodes, goals)
+        b, lb = p.h.shot(nodes, goals)
+        assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+        sa, ca = p.o.expand(nodes, goals)
+        sb, cb = p.h.expand(nodes, goals)
+        assert np.array_equal(ca, cb)
+        assert sa.tobytes() == sb.tobytes()
+    assert parking_dubins.o.shot(*_nodes(parking_dubins, 1500, 81))[0].mean() > 0.02
+
+
+def test_dubins_plan(parking_dubins, maze_dubins_default):
+    for p, seed, n in ((parking_dubins, 91, 32), (maze_dubins_default, 92, 32)):
+        s, g = p.free_poses(n, seed), p.free_poses(n, seed + 1)
+        res = _plan_compare(p, s, g)
+        assert len(res) == n
