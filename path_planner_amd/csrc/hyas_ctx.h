@@ -43,7 +43,7 @@ struct hyas_ctx
     uint16_t *d_cell_idx = nullptr;
     int32_t *d_fp = nullptr;
     uint64_t *d_occ_tiles = nullptr;
-    uint4 *d_fp_pack = nullptr;
+    hyas::FpPack *d_fp_pack = nullptr;
     float *d_table = nullptr;
     float *d_tab_xs = nullptr, *d_tab_ys = nullptr, *d_tab_ts = nullptr;
     double *d_seg = nullptr;

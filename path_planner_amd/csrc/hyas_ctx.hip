@@ -416,8 +416,8 @@ static int upload_footprint_forms(hyas_ctx *c)
         return rc;
     m.occ_tiles = c->d_occ_tiles, m.tiles_x = tx;
     const size_t entries = c->fp.size() / 129;
-    std::vector<uint4> pack(entries);
-    bool fits = entries * sizeof(uint4) <= 150 * 1024; // the kernel keeps the whole table in LDS
+    std::vector<FpPack> pack(entries);
+    bool fits = entries * sizeof(FpPack) <= 150 * 1024; // the kernel keeps the whole table in LDS
     for (size_t e = 0; e < entries && fits; ++e)
     {
         const int32_t *src = &c->fp[e * 129];

@@ -56,6 +56,12 @@ struct Quad
 HD F2 qv(const Quad &q, int i) { return f2(q.vx[i & 3], q.vy[i & 3]); }
 
 // Everything a kernel needs to know about the map and the planner settings.
+// one packed footprint list: byte 0 = len, then (dx, dy) as int8 pairs
+struct alignas(16) FpPack
+{
+    uint32_t w[4];
+};
+
 struct DevMap
 {
     // costmap_2d state (double, as Costmap2D keeps it)
@@ -102,7 +108,7 @@ struct DevMap
     //  fp_pack:   16 bytes per list {len, (dx, dy) as int8 x 7}; null when a list is longer or an offset wider
     const uint64_t *occ_tiles;
     uint32_t tiles_x;
-    const uint4 *fp_pack;
+    const FpPack *fp_pack;
     uint32_t fp_entries;
     int32_t fp_max_len;
     // motion set
@@ -386,10 +392,14 @@ HD void vehicle_corners(const DevMap &m, float x, float y, float t, F2 c[4])
 // Where the kernels read obstacle quads from: global memory (default) or a
 // workgroup-local copy.  Fetch returns the quad by value so the out-of-line
 // geometry routines below work on registers, not on pointers.
+// stop() lets a caller whose overall answer is already decided (another lane
+// found a collision) cut the list walks short; hit() announces a collision.
 struct GlobalQuads
 {
     const Quad *p;
     HD Quad operator()(uint32_t i) const { return p[i]; }
+    HD bool stop() const { return false; }
+    HD void hit() const {}
 };
 
 // src/utility.cpp:956-966 + :528-540 for a 4-corner vehicle against one quad.
@@ -438,11 +448,16 @@ HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float
 #pragma unroll 1
     for (uint32_t k = off[key], e = off[key + 1]; k < e; ++k)
     {
+        if (quads.stop())
+            return true; // the caller no longer needs this verdict
         const Quad q = quads(idx[k]);
         if (q.xmax < bxmin || q.ymax < bymin || bxmax < q.xmin || bymax < q.ymin)
             continue;
         if (vehicle_hits_quad(c[0], c[1], c[2], c[3], q))
+        {
+            quads.hit();
             return false;
+        }
     }
     return true;
 }
@@ -559,11 +574,16 @@ HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, 
 #pragma unroll 1
         for (uint32_t k = off[key], end = off[key + 1]; k < end; ++k)
         {
+            if (quads.stop())
+                return true; // the caller no longer needs this verdict
             const uint16_t ent = idx[k];
             const Quad q = quads(ent & 0x7fffu);
             // bit 15 (pruned lists only): only the ray-casting test can fire
             if ((pruned && (ent & 0x8000u)) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad(r, m.half_wid, s, e, q))
+            {
+                quads.hit();
                 return false;
+            }
         }
     }
     return true;

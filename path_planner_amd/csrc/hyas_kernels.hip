@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(1024) k_collision_footprint_tiles(DevMap m, co
 {
     extern __shared__ uint4 s_fp[];
     for (uint32_t i = threadIdx.x; i < m.fp_entries; i += blockDim.x)
-        s_fp[i] = m.fp_pack[i];
+        s_fp[i] = reinterpret_cast<const uint4 *>(m.fp_pack)[i];
     __syncthreads();
     const int pr = m.pr;
     const size_t groups = n / 4;
@@ -323,7 +323,14 @@ struct StepQuads
 {
     const Quad *lds; // null: no local copy
     const Quad *glb;
+    volatile int *flag; // workgroup flag "a sample of this shot collides" (null: every verdict is wanted)
     __device__ __forceinline__ Quad operator()(uint32_t i) const { return lds ? lds[i] : glb[i]; }
+    __device__ __forceinline__ bool stop() const { return flag && *flag != 0; }
+    __device__ __forceinline__ void hit() const
+    {
+        if (flag)
+            *flag = 1;
+    }
 };
 #ifndef STEP_MIN_WAVES
 #define STEP_MIN_WAVES 4 // waves per SIMD the register allocation must allow: three workgroups per CU
@@ -445,7 +452,7 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
         for (uint32_t i = tid; i < m.n_quads * 16u; i += ROUND_THREADS)
             dst[i] = src[i];
     }
-    return StepQuads{quads_local ? s_quads : nullptr, m.quads};
+    return StepQuads{quads_local ? s_quads : nullptr, m.quads, nullptr};
 }
 
 template <int MODE>
@@ -548,7 +555,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     __shared__ rs::Prefix s_prefix;
     __shared__ db::Path s_dubins;
     __shared__ float s_xyt[SHOT_THREADS + 1][3]; // [0] = the sample in front of this batch
-    __shared__ int s_hit;
+    __shared__ volatile int s_hit;
     __shared__ unsigned int s_first, s_lists;
     constexpr bool RS = CURVE == HYAS_CURVE_RS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,7 +572,9 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         c0 = clock64();
     const hyas_goal goal = goals[node.query];
     const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
-    const StepQuads sq = stage_quads(m, s_quads, tid); // visible after the barrier that ends phase 1
+    StepQuads sq = stage_quads(m, s_quads, tid); // visible after the barrier that ends phase 1
+    if (!STATS)
+        sq.flag = &s_hit; // one colliding sample decides the shot: the other lanes stop walking their lists
 
     // ---- phase 1 ------------------------------------------------------------
     if (!RS)

@@ -62,7 +62,9 @@ struct CellMap
         slots.assign(cap, Slot{-1, 999.f, 0, 0});
         used = 0;
     }
-    static size_t hash(int32_t k) { return (size_t)((uint32_t)k * 2654435761u); }
+    // Successors of a node fall into the same or neighbouring cells: keeping neighbouring keys in neighbouring
+    // slots makes the lookups of one expansion share cache lines.  Keys are dense, so runs rarely collide.
+    static size_t hash(int32_t k) { return (size_t)(uint32_t)k; }
     Slot *find(int32_t key)
     {
         size_t mask = slots.size() - 1, i = hash(key) & mask;
@@ -134,9 +136,10 @@ struct Driver
     // through the reference's own comparison, so the answer is the linear
     // scan's answer.
     static int32_t bucket_coord(float v) { return (int32_t)std::floor((double)v * 10.0); }
+    // buckets of one row are adjacent in memory: the 3x3 neighbourhood of a lookup touches three short runs
     static size_t bucket_hash(int32_t bx, int32_t by, size_t mask)
     {
-        return (size_t)(((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349663u)) & mask;
+        return (size_t)((uint32_t)by * 2654435761u + (uint32_t)bx) & mask;
     }
     void dup_link(Query &q, int32_t id)
     {
@@ -175,18 +178,11 @@ struct Driver
     {
         const int32_t bx = bucket_coord(x), by = bucket_coord(y);
         const size_t mask = q.dup_head.size() - 1;
-        size_t seen[9];
-        int nseen = 0;
-        for (int dx = -1; dx <= 1; ++dx)
-            for (int dy = -1; dy <= 1; ++dy)
+        // two neighbours may share a bucket; scanning it twice does not change the answer
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
             {
-                size_t b = bucket_hash(bx + dx, by + dy, mask);
-                bool again = false;
-                for (int k = 0; k < nseen; ++k)
-                    again |= (seen[k] == b);
-                if (again)
-                    continue;
-                seen[nseen++] = b;
+                const size_t b = bucket_hash(bx + dx, by + dy, mask);
                 for (int32_t id = q.dup_head[b]; id >= 0; id = q.arena[id].dup_next)
                 {
                     const SNode &e = q.arena[id];
@@ -552,7 +548,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
                 flood_2d(c, q.goal.x, q.goal.y, h_twod + i * twod);
                 q.cells.init(1024);
-                q.dup_head.assign(1 << 14, -1);
+                q.dup_head.assign(1 << 11, -1);
                 q.arena.reserve(1024);
             }
         });
