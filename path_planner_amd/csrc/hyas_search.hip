@@ -390,7 +390,7 @@ class Pool
         }
         fn_ = &fn;
         count_ = count;
-        chunk_ = std::max<size_t>(16, count / (size_t)(n_ * 4));
+        chunk_ = std::max<size_t>(4, count / (size_t)(n_ * 4));
         next_.store(0, std::memory_order_relaxed);
         pending_.store(n_ - 1, std::memory_order_relaxed);
         gen_.fetch_add(1, std::memory_order_acq_rel);
@@ -477,7 +477,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t chunk_cap = 4096;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
-    size_t n_groups = 2; // query groups in flight at once
+    size_t n_groups = 3; // query groups in flight at once
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
     const size_t twod = c->twod_size;
@@ -607,6 +607,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 G[gi].live.push_back((uint32_t)i);
         }
         std::vector<uint8_t> wants(cn);
+        std::vector<StepIn> stage(cn); // next round's input of every query, filled by the worker that popped it
         double t_host = 0, t_launch = 0, t_wait = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // each group owns a stream and a slice of the staging block, laid out for the group's current size so the
@@ -634,21 +635,24 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     Query &q = Q[g.live[k]];
                     if (have_results)
                         D.consume(q, r_ok[k], r_len[k], r_cnt[k], r_succ + k * K);
-                    wants[g.live[k]] = (!q.done && D.advance(q)) ? 1 : 0;
+                    const uint32_t qi = g.live[k];
+                    wants[qi] = (!q.done && D.advance(q)) ? 1 : 0;
+                    if (wants[qi])
+                    {
+                        const SNode &nd = q.arena[q.cur]; // still in this worker's cache
+                        stage[qi] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, q.shoot ? 1u : 0u, 0};
+                    }
                 }
             });
             g.keep.clear();
             for (uint32_t qi : g.live)
                 if (wants[qi])
+                {
+                    h_in[g.s0 + g.keep.size()] = stage[qi];
                     g.keep.push_back(qi);
+                }
             g.live.swap(g.keep); // queries that finished drop out
             g.ns = g.live.size();
-            for (size_t k = 0; k < g.ns; ++k)
-            {
-                const Query &q = Q[g.live[k]];
-                const SNode &nd = q.arena[q.cur];
-                h_in[g.s0 + k] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, g.live[k], q.shoot ? 1u : 0u, 0};
-            }
             t_host += now() - t0;
             return g.ns != 0;
         };
