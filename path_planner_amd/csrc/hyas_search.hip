@@ -370,8 +370,9 @@ class Pool
     explicit Pool(int nthreads) : n_(std::max(1, nthreads))
     {
         for (int i = 1; i < n_; ++i)
-            th_.emplace_back([this] { worker(); });
+            th_.emplace_back([this, i] { worker(i); });
     }
+    int size() const { return n_; }
     ~Pool()
     {
         stop_.store(true, std::memory_order_release);
@@ -399,6 +400,24 @@ class Pool
             cpu_relax();
     }
 
+    // fn(w) once on every thread, w = 0 (the caller) .. size()-1: the same w is always the same thread, so
+    // data a thread touched last round is still in its cache
+    void run_parts(const std::function<void(int)> &fn)
+    {
+        if (n_ == 1)
+        {
+            fn(0);
+            return;
+        }
+        part_fn_ = &fn;
+        pending_.store(n_ - 1, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_acq_rel);
+        fn(0);
+        while (pending_.load(std::memory_order_acquire) != 0)
+            cpu_relax();
+        part_fn_ = nullptr;
+    }
+
   private:
     static void cpu_relax() { __builtin_ia32_pause(); }
     void work()
@@ -411,7 +430,7 @@ class Pool
             (*fn_)(b, std::min(count_, b + chunk_));
         }
     }
-    void worker()
+    void worker(int self)
     {
         uint64_t seen = 0;
         for (;;)
@@ -427,7 +446,10 @@ class Pool
             seen = gen_.load(std::memory_order_acquire);
             if (stop_.load(std::memory_order_acquire))
                 return;
-            work();
+            if (part_fn_)
+                (*part_fn_)(self);
+            else
+                work();
             pending_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
@@ -438,6 +460,7 @@ class Pool
     std::atomic<size_t> next_{0};
     std::atomic<int> pending_{0};
     const std::function<void(size_t, size_t)> *fn_ = nullptr;
+    const std::function<void(int)> *part_fn_ = nullptr;
     size_t count_ = 0, chunk_ = 1;
 };
 
@@ -477,7 +500,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t chunk_cap = 4096;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
-    size_t n_groups = 3; // query groups in flight at once
+    size_t n_groups = 4; // query groups in flight at once
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
     const size_t twod = c->twod_size;
@@ -586,6 +609,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         if ((rc = ensure_scratch(c, o_twod_host, off)) != HYAS_OK)
             return rc;
         ds = (char *)c->d_scratch;
+        char *hd = nullptr; // the pinned host block as the GPU addresses it
+        HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
         HYAS_HIP(c, hipMemcpyAsync(c->d_twod, h_twod, cn * twod * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HYAS_HIP(c, hipMemcpyAsync(ds + o_goal, h_goal, cn * sizeof(hyas_goal), hipMemcpyHostToDevice, c->stream));
         HYAS_HIP(c, hipStreamSynchronize(c->stream));
@@ -607,6 +632,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 G[gi].live.push_back((uint32_t)i);
         }
         std::vector<uint8_t> wants(cn);
+        std::vector<size_t> bounds;
         std::vector<StepIn> stage(cn); // next round's input of every query, filled by the worker that popped it
         double t_host = 0, t_launch = 0, t_wait = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -629,8 +655,19 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
             const float *r_len = (const float *)(hs + p_len);
             const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
-            pool.run(g.live.size(), [&](size_t a, size_t b) {
-                for (size_t k = a; k < b; ++k)
+            // every query belongs to one worker for the whole search (a block of its group's queries): its heap, cell map
+            // and duplicate hash stay in that core's cache from round to round
+            const int nw = pool.size();
+            bounds.assign(nw + 1, g.live.size());
+            bounds[0] = 0;
+            {
+                int w = 1;
+                for (size_t k = 0; k < g.live.size() && w < nw; ++k)
+                    while (w < nw && ((size_t)g.live[k] - g.s0) * nw >= (size_t)w * gcap)
+                        bounds[w++] = k;
+            }
+            pool.run_parts([&](int w) {
+                for (size_t k = bounds[w]; k < bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
                     if (have_results)
@@ -656,22 +693,22 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             t_host += now() - t0;
             return g.ns != 0;
         };
-        // one upload, one launch and one download per round
+        // One launch per round.  The kernel reads the popped nodes from, and writes its results to, the pinned
+        // host block directly (the records are a few KB: no staging copies, no copy engines in the round trip).
         auto launch = [&](Group &g, int gi) -> int {
             hipStream_t st = c->round_stream[gi];
             hipEvent_t *ev = c->round_ev[gi];
             const size_t s0 = g.s0, ns = g.ns;
             const double t0 = now();
             size_t p_succ, p_len, p_ok, p_cnt;
-            const size_t bytes = slice(g, p_succ, p_len, p_ok, p_cnt);
-            const StepIn *d_in = (const StepIn *)(ds + o_in) + s0;
-            HYAS_HIP(c, hipMemcpyAsync(ds + o_in + s0 * sizeof(StepIn), h_in + s0, ns * sizeof(StepIn), hipMemcpyHostToDevice, st));
+            (void)slice(g, p_succ, p_len, p_ok, p_cnt);
+            const StepIn *d_in = (const StepIn *)(hd + o_in) + s0;
             (void)hipEventRecord(ev[0], st);
-            launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(ds + p_ok),
-                         (float *)(ds + p_len), (uint8_t *)(ds + p_cnt), (hyas_succ *)(ds + p_succ), c->stats_on ? c->d_stats : nullptr,
+            launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
+                         (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
                          c->stats_mode, st);
             (void)hipEventRecord(ev[1], st);
-            HYAS_HIP(c, hipMemcpyAsync(hs + p_succ, ds + p_succ, bytes, hipMemcpyDeviceToHost, st));
+            HYAS_HIP(c, hipGetLastError());
             g.inflight = true;
             t_launch += now() - t0;
             return HYAS_OK;
