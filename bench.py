@@ -139,10 +139,11 @@ def main():
         avg_ms = kern_ms / max(kern_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
-        tf = ROOT / "profiles" / "step_kernel_traffic.json"
-        if tf.exists():
+        # HBM-side bytes per launch from the rocprofv3 counter passes (profiles/collect_traffic.sh), newest file
+        for tf in sorted((ROOT / "profiles").glob("r*_step_kernel_traffic.json"), reverse=True):
             try:
                 traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+                break
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -26,12 +26,13 @@
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define HY_HD __host__ __device__ inline
-/* the larger routines are real calls on the device: inlining every sin/cos/
- * atan2 into a kernel multiplies its code size past the instruction cache */
-#ifdef HYAS_INLINE_MATH
-#define HY_HD_CALL HY_HD
-#else
+/* the larger routines (sin, cos, atan2, fmod): inlined by default, which measured faster in the
+ * search kernels than real calls (no register save/restore through scratch memory);
+ * -DHYAS_MATH_CALLS makes them calls, for smaller code */
+#ifdef HYAS_MATH_CALLS
 #define HY_HD_CALL __host__ __device__ inline __attribute__((noinline))
+#else
+#define HY_HD_CALL HY_HD
 #endif
 #else
 #define HY_HD inline
