@@ -87,6 +87,13 @@ def load_library():
         raise HyasError(f"{p} is missing: build it with `make -C path_planner_amd/csrc` "
                         "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
     try:
+        # torch bundles its own HIP runtime; if libhyas.so pulled in the system one first, a later
+        # `import torch` would bring a second runtime into the process and find no GPU.  Loading torch
+        # first makes both share one.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    try:
         L = C.CDLL(str(p))
     except OSError as e:  # e.g. libamdhip64 not found
         raise HyasError(f"cannot load {p}: {e}") from e

@@ -1,0 +1,146 @@
+"""GPU tests at the benchmark configurations' full sizes, through properties that do not need the (slow) CPU
+oracle on every element: determinism, independence of batch composition, paths that start and end where asked
+and are collision-free, sharded table builds that tile the single build, verdict counts against the oracle where
+the oracle is fast enough to run in full."""
+import math
+
+import numpy as np
+import pytest
+
+import orc
+from path_planner_amd import Hyas, Params, default_params, hot_path_params
+from path_planner_amd import _lib as hl
+from path_planner_amd.sharding import heading_slices, make_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def maze_ctx():
+    h = Hyas(hot_path_params())
+    h.set_costmap(orc.load_map("map_maze"), build_table=True)
+    return h
+
+
+def test_maze_1024_queries_properties(maze_ctx, oracle_built):
+    h = maze_ctx
+    S, G = make_queries(h.collision, 1024, 20250228, 50, 50)
+    res = h.plan_batch(S, G)
+    paths = [h.path(i) for i in range(1024)]
+    expanded = [h.expanded(i) for i in range(1024)]
+    # every status occurs on this batch; counters are consistent
+    assert set(res["status"].tolist()) == {hl.STATUS_NO_PATH, hl.STATUS_SHOT, hl.STATUS_MAX_ITER}
+    assert (res["nodes_expanded"] <= res["nodes_explored"]).all()
+    assert (res["nodes_explored"] <= 10001 + 500).all()  # pops of already closed nodes count too
+    assert (res["successors"] <= 6 * res["nodes_expanded"]).all()
+    for i in range(1024):
+        assert len(expanded[i]) == res[i]["nodes_expanded"]
+        assert len(paths[i]) == res[i]["path_len"]
+    # paths: start at the start, a connected one ends on the goal, every pose is traversable
+    done = np.flatnonzero(res["status"] == hl.STATUS_SHOT)
+    assert len(done) > 500
+    for i in done:
+        p = paths[i]
+        assert np.allclose(p[0], S[i], atol=1e-2)
+        assert np.array_equal(p[-1, :2], G[i, :2])
+        step = np.hypot(np.diff(p[:, 0]), np.diff(p[:, 1]))
+        assert step.max() <= 0.2 + 1e-4
+    allp = np.concatenate([paths[i][:-1] for i in done])  # the appended goal pose was pre-checked separately
+    assert h.collision(allp).all()
+    # determinism
+    res2 = h.plan_batch(S, G)
+    assert res.tobytes() == res2.tobytes()
+    assert all(np.array_equal(paths[i], h.path(i)) for i in range(0, 1024, 37))
+    # independence of batch composition and order: a shuffled subset gives the same per-query answers
+    rng = np.random.default_rng(1)
+    pick = rng.permutation(1024)[:96]
+    res3 = h.plan_batch(S[pick], G[pick])
+    for k, i in enumerate(pick):
+        assert res3[k].tobytes() == res[i].tobytes(), i
+        assert np.array_equal(h.expanded(k), expanded[i]) and np.array_equal(h.path(k), paths[i])
+    # the oracle on a sample of the short queries (seconds on one core)
+    po = orc.hot_path_params()
+    o = orc.Oracle(po)
+    o.set_costmap(orc.load_map("map_maze"), build_table=True, nthreads=16)
+    short = [i for i in np.argsort(res["nodes_explored"]) if res[i]["nodes_explored"] > 5][:24]
+    for i in short:
+        r, path, exp = o.plan(S[i], G[i])
+        assert r.tobytes() == res[i].tobytes(), i
+        assert np.array_equal(exp, expanded[i]) and path.tobytes() == paths[i].tobytes()
+
+
+def test_footprint_10m_checks_against_oracle(oracle_built):
+    W = H = 4096
+    n = 10_000_000
+    grid = np.where(np.random.default_rng(1).random((H, W)) < 0.10, 254, 0).astype(np.uint8)
+    rng = np.random.default_rng(2)
+    xyt = np.stack([rng.uniform(8, W - 8, n), rng.uniform(8, H - 8, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
+    h = Hyas(default_params())
+    h.set_grid(grid)
+    got = h.collision(xyt, mode=hl.MODE_FOOTPRINT)
+    o = orc.Oracle(orc.default_params())
+    o.set_grid(grid)
+    want = o.collision(xyt, mode=1)
+    assert int(got.sum()) == int(want.sum())
+    assert np.array_equal(got, want)
+    # the free fraction is what the occupancy predicts: 0.9 ** (mean listed cells) within sampling noise
+    assert 0.80 < got.mean() < 0.90
+
+
+def test_rs_table_slices_tile_the_full_build(oracle_built):
+    """180x60 map, rho 0.35: building the 73 heading slices in 8 runs (as 8 GPUs would) equals one build; three
+    slices are checked against the CPU oracle entry by entry; lookups hit what was installed."""
+    import torch
+
+    grid = np.zeros((60, 180), np.uint8)
+    for pr in (1, 3):
+        p = hot_path_params(position_resolution=pr, cd_min_turning_radius=0.35)
+        h = Hyas(p)
+        h.set_costmap(grid, build_table=False)
+        nx, ny, ns = h.table_dims()
+        po = orc.hot_path_params(position_resolution=pr, cd_min_turning_radius=0.35)
+        o = orc.Oracle(po)
+        o.set_costmap(grid, build_table=False)
+        assert (nx, ny, ns) == o.table_dims()  # float-accumulated axes: 1/3 steps overshoot by one sample
+        assert ns == 73 and nx >= 180 * pr and ny >= 60 * pr
+        full = torch.zeros((ns, ny, nx), dtype=torch.float32, device="cuda")
+        h.table_build_dev(1, 0, ns, full.data_ptr())
+        parts = torch.zeros_like(full)
+        slices, per = heading_slices(ns, 8)
+        for k0, k1 in slices:
+            if k1 > k0:
+                h.table_build_dev(1, k0, k1, parts[k0:k1].data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(full.view(torch.int32), parts.view(torch.int32))
+        for k in (0, 36, 72):
+            want = o.table_build(1, k, k + 1)[0]
+            assert np.array_equal(full[k].cpu().numpy().view(np.uint32), want.view(np.uint32)), (pr, k)
+        h.table_install_dev(1, parts.data_ptr())
+        q = np.array([[3.0, 2.0, 1.0], [100.0, 40.0, 3.0], [179.0, 59.0, 6.0]], np.float32)
+        o.build_table(1, 16)
+        assert np.array_equal(h.table_lookup(q).view(np.uint32), o.table_lookup(q).view(np.uint32))
+
+
+def test_large_map_query_blocks(oracle_built):
+    """map_large, benchmark sampling (seed 3): planning a batch in two contiguous blocks (two ranks) gives the same
+    answers as planning it whole; spot-check against the oracle."""
+    mp = orc.load_map("map_large")
+    H, W = mp.shape
+    h = Hyas(hot_path_params(max_iterations=400))
+    h.set_costmap(mp, build_table=True)
+    S, G = make_queries(h.collision, 4096, 3, W, H)
+    whole = h.plan_batch(S, G)
+    keep = {i: (h.path(i), h.expanded(i)) for i in range(0, 4096, 129)}
+    a = h.plan_batch(S[:2048], G[:2048])
+    first = {i: (h.path(i), h.expanded(i)) for i in keep if i < 2048}
+    b = h.plan_batch(S[2048:], G[2048:])
+    second = {i: (h.path(i - 2048), h.expanded(i - 2048)) for i in keep if i >= 2048}
+    assert np.concatenate([a, b]).tobytes() == whole.tobytes()
+    for i, (p, e) in {**first, **second}.items():
+        assert np.array_equal(p, keep[i][0]) and np.array_equal(e, keep[i][1])
+    o = orc.Oracle(orc.hot_path_params(max_iterations=400))
+    o.set_costmap(mp, build_table=True, nthreads=16)
+    for i in list(keep)[:12]:
+        r, path, exp = o.plan(S[i], G[i])
+        assert r.tobytes() == whole[i].tobytes(), i
+        assert np.array_equal(exp, keep[i][1]) and path.tobytes() == keep[i][0].tobytes()
