@@ -80,11 +80,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # rehearsal on a one-GPU box: HYAS_BENCH_BACKEND=gloo HYAS_BENCH_DEVICE=0 puts every rank on GPU 0 without RCCL
+    backend = os.environ.get("HYAS_BENCH_BACKEND", "nccl")
+    if "HYAS_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["HYAS_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the expansion path has no CPU fallback")
 

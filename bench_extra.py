@@ -30,11 +30,17 @@ def _dist_setup():
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU: the expansion path has no CPU fallback")
+    backend = os.environ.get("HYAS_BENCH_BACKEND", "nccl")  # "gloo" + HYAS_BENCH_DEVICE=0: rehearsal on one GPU
+    if "HYAS_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["HYAS_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     return torch, dist, rank, local_rank, world
 
 

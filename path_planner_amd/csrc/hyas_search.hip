@@ -8,9 +8,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <thread>
 
 #include <sched.h>
@@ -376,7 +378,7 @@ class Pool
     ~Pool()
     {
         stop_.store(true, std::memory_order_release);
-        gen_.fetch_add(1, std::memory_order_acq_rel);
+        publish();
         for (auto &t : th_)
             t.join();
     }
@@ -394,7 +396,7 @@ class Pool
         chunk_ = std::max<size_t>(4, count / (size_t)(n_ * 4));
         next_.store(0, std::memory_order_relaxed);
         pending_.store(n_ - 1, std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_acq_rel);
+        publish();
         work();
         while (pending_.load(std::memory_order_acquire) != 0)
             cpu_relax();
@@ -411,7 +413,7 @@ class Pool
         }
         part_fn_ = &fn;
         pending_.store(n_ - 1, std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_acq_rel);
+        publish();
         fn(0);
         while (pending_.load(std::memory_order_acquire) != 0)
             cpu_relax();
@@ -420,6 +422,16 @@ class Pool
 
   private:
     static void cpu_relax() { __builtin_ia32_pause(); }
+    // announces new work; wakes the workers that gave up spinning
+    void publish()
+    {
+        gen_.fetch_add(1, std::memory_order_acq_rel);
+        if (sleepers_.load(std::memory_order_acquire) != 0)
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            cv_.notify_all();
+        }
+    }
     void work()
     {
         for (;;)
@@ -435,13 +447,20 @@ class Pool
         uint64_t seen = 0;
         for (;;)
         {
+            // rounds are tens of microseconds apart: spin for about that long, then block, so that a machine
+            // with fewer free CPUs than workers does not burn its time slices in spin loops
             int spins = 0;
             while (gen_.load(std::memory_order_acquire) == seen)
             {
-                if (++spins > 20000)
-                    std::this_thread::yield();
-                else
+                if (++spins < 6000)
+                {
                     cpu_relax();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu_);
+                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
             }
             seen = gen_.load(std::memory_order_acquire);
             if (stop_.load(std::memory_order_acquire))
@@ -459,6 +478,9 @@ class Pool
     std::atomic<bool> stop_{false};
     std::atomic<size_t> next_{0};
     std::atomic<int> pending_{0};
+    std::atomic<int> sleepers_{0};
+    std::mutex mu_;
+    std::condition_variable cv_;
     const std::function<void(size_t, size_t)> *fn_ = nullptr;
     const std::function<void(int)> *part_fn_ = nullptr;
     size_t count_ = 0, chunk_ = 1;
@@ -477,6 +499,13 @@ int host_threads()
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0)
         hc = (unsigned)CPU_COUNT(&set);
+    // one process per GPU: the ranks of a node share its CPUs
+    if (const char *e = std::getenv("LOCAL_WORLD_SIZE"))
+    {
+        int lw = std::atoi(e);
+        if (lw > 1)
+            hc = std::max(2u, hc / (unsigned)lw);
+    }
     return (int)std::min<unsigned>(std::max<unsigned>(hc, 1), 16);
 }
 
