@@ -56,6 +56,8 @@ RESULT_DT = np.dtype([("status", "i4"), ("nodes_explored", "i4"), ("nodes_expand
                       ("path_len", "i4"), ("g_final", "f4"), ("shot_length", "f4"), ("path_length", "f4")])
 
 STATUS_NO_PATH, STATUS_GOAL, STATUS_SHOT, STATUS_MAX_ITER, STATUS_BAD_POSE = range(5)
+# return codes of include/hyas.h
+OK, EINVAL, ENOMEM, ENODEV, ESTATE, ERANGE = 0, -22, -12, -19, -1, -34
 MODE_POLYGON, MODE_FOOTPRINT = 0, 1
 
 # every symbol include/hyas.h declares
@@ -293,7 +295,8 @@ class Hyas:
         starts = np.ascontiguousarray(starts, np.float32).reshape(-1, 3)
         goals = np.ascontiguousarray(goals, np.float32).reshape(-1, 3)
         n = starts.shape[0]
-        assert goals.shape[0] == n
+        if goals.shape[0] != n:
+            raise HyasError(f"plan_batch: {n} starts but {goals.shape[0]} goals")
         res = np.zeros(n, RESULT_DT)
         self._check(self.L.hyas_plan_batch(self.h, _vp(starts), _vp(goals), n, _vp(res)), "hyas_plan_batch")
         return res

@@ -341,3 +341,45 @@ def test_dubins_plan(parking_dubins, maze_dubins_default):
         s, g = p.free_poses(n, seed), p.free_poses(n, seed + 1)
         res = _plan_compare(p, s, g)
         assert len(res) == n
+
+
+def test_abi_error_behaviour():
+    """Call-order and argument errors come back as codes with a message; nothing crashes, nothing is computed."""
+    import ctypes as C
+
+    L = hl.load_library()
+    # unsupported parameter sets are refused at creation
+    for kw in (dict(adaptive_step_size=1), dict(adaptive_steering_angle_and_step_size=1), dict(curve_type=2),
+               dict(vehicle_width=-1.0), dict(min_turning_radius=0.0), dict(number_of_successors=0), dict(headings=0)):
+        p = hl.hot_path_params(**kw)
+        assert L.hyas_create(C.byref(p), 0) is None, kw
+    p = hl.hot_path_params()
+    assert L.hyas_create(C.byref(p), 99) is None  # no such device
+    h = Hyas(hl.hot_path_params(position_resolution=1))
+    buf = np.zeros(64, np.float32)
+    out = np.zeros(64, np.uint8)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    # before a costmap: state error
+    assert L.hyas_collision_batch(h.h, 0, vp(buf), None, 4, vp(out)) == hl.ESTATE
+    assert L.hyas_plan_batch(h.h, vp(buf), vp(buf), 1, vp(out)) == hl.ESTATE
+    assert L.hyas_twod_size(h.h) == hl.ESTATE
+    assert L.hyas_set_costmap(h.h, None, 4, 4, 1.0, 0.0, 0.0, 0) == hl.EINVAL
+    assert L.hyas_set_costmap(h.h, vp(out), 0, 4, 1.0, 0.0, 0.0, 0) == hl.EINVAL
+    assert b"" != L.hyas_last_error(h.h)
+    # costmap without table: searching needs the table
+    h.set_costmap(orc.load_map("map_small"), build_table=False)
+    assert L.hyas_plan_batch(h.h, vp(buf), vp(buf), 1, vp(out)) == hl.ESTATE
+    assert L.hyas_collision_batch(h.h, 7, vp(buf), None, 4, vp(out)) == hl.EINVAL  # unknown mode
+    assert L.hyas_collision_batch(h.h, 0, None, None, 4, vp(out)) == hl.EINVAL
+    assert L.hyas_collision_batch(h.h, 0, vp(buf), None, 0, vp(out)) == hl.OK  # empty batch
+    # grid-only contexts refuse the polygon test
+    g = Hyas(hl.default_params())
+    g.set_grid(np.zeros((16, 16), np.uint8))
+    assert L.hyas_collision_batch(g.h, 0, vp(buf), None, 4, vp(out)) == hl.ESTATE
+    assert L.hyas_collision_batch(g.h, 1, vp(buf), None, 4, vp(out)) == hl.OK
+    # an empty plan batch is fine once everything is set up
+    h.set_costmap(orc.load_map("map_small"), build_table=True)
+    res = h.plan_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(res) == 0
+    with pytest.raises(hl.HyasError):
+        h.plan_batch(np.zeros((2, 3), np.float32), np.zeros((3, 3), np.float32))
