@@ -39,13 +39,8 @@ struct HeapItem
     uint32_t seq;
     int32_t node;
 };
-// Open list order: lowest f = g + h first (CompareNodes,
-// include/hybrid_a_star.h:31-43); equal f: earliest push first.  (Boost's
-// binomial heap leaves the order of equal keys unspecified.)
-struct HeapLess
-{
-    bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f > b.f || (a.f == b.f && a.seq > b.seq); }
-};
+// Open list order: lowest f = g + h first (CompareNodes, include/hybrid_a_star.h:31-43); equal f: earliest
+// push first.  (Boost's binomial heap leaves the order of equal keys unspecified.)  See Driver::before().
 
 // idx -> {g, open, closed}: the three Node3D fields GetPath reads back from
 // nodes3D[] (:101, :110, :264, :271).  Open addressing, grows at 50 % load.
@@ -196,18 +191,23 @@ struct Driver
     }
 
     // ---- heap ------------------------------------------------------------
+    // Binary min-heap on (f, seq), a strict total order: the pop sequence does not depend on the heap's shape.
+    struct After
+    {
+        bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f > b.f || (a.f == b.f && a.seq > b.seq); }
+    };
     void push(Query &q, const SNode &n)
     {
         q.arena.push_back(n);
         int32_t id = (int32_t)q.arena.size() - 1;
         q.heap.push_back(HeapItem{n.g + n.h, q.seq++, id}); // getTotalCost(), include/node3d.h:36
-        std::push_heap(q.heap.begin(), q.heap.end(), HeapLess());
+        std::push_heap(q.heap.begin(), q.heap.end(), After());
         dup_insert(q, id);
     }
     void pop(Query &q)
     {
         dup_remove(q, q.heap.front().node);
-        std::pop_heap(q.heap.begin(), q.heap.end(), HeapLess());
+        std::pop_heap(q.heap.begin(), q.heap.end(), After());
         q.heap.pop_back();
     }
 
@@ -338,6 +338,18 @@ struct Driver
         const SNode pred = q.arena[pid];
         q.res.successors += count >> 4; // motion-set entries that received a verdict
         count &= 15;
+        // the lookups below miss the cache independently of each other: request all their lines first
+        {
+            const size_t cmask = q.cells.slots.size() - 1, dmask = q.dup_head.size() - 1;
+            for (int k = 0; k < count; ++k)
+            {
+                const hyas_succ &s = succ[k];
+                __builtin_prefetch(&q.cells.slots[CellMap::hash(s.idx) & cmask]);
+                const int32_t bx = bucket_coord(s.x), by = bucket_coord(s.y);
+                for (int dy = -1; dy <= 1; ++dy)
+                    __builtin_prefetch(&q.dup_head[bucket_hash(bx, by + dy, dmask)]);
+            }
+        }
         for (int k = 0; k < count; ++k)
         {
             const hyas_succ &s = succ[k];
@@ -663,7 +675,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::vector<uint8_t> wants(cn);
         std::vector<size_t> bounds;
         std::vector<StepIn> stage(cn); // next round's input of every query, filled by the worker that popped it
-        double t_host = 0, t_launch = 0, t_wait = 0;
+        double t_host = 0, t_launch = 0, t_wait = 0, part_max = 0, part_mean = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // each group owns a stream and a slice of the staging block, laid out for the group's current size so the
         // results of a round come back in one copy
@@ -684,16 +696,18 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
             const float *r_len = (const float *)(hs + p_len);
             const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
-            // every query belongs to one worker for the whole search (a block of its group's queries): its heap, cell map
-            // and duplicate hash stay in that core's cache from round to round
+            // equal shares of the group's live queries, in index order: a query stays with the same worker from
+            // round to round (its heap, cell map and duplicate hash stay in that core's cache) and only moves to a
+            // neighbour when queries in front of it finish
             const int nw = pool.size();
-            bounds.assign(nw + 1, g.live.size());
-            bounds[0] = 0;
+            bounds.resize(nw + 1);
+            for (int w = 0; w <= nw; ++w)
+                bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             {
-                int w = 1;
-                for (size_t k = 0; k < g.live.size() && w < nw; ++k)
-                    while (w < nw && ((size_t)g.live[k] - g.s0) * nw >= (size_t)w * gcap)
-                        bounds[w++] = k;
+                size_t mx = 0;
+                for (int w = 0; w < nw; ++w)
+                    mx = std::max(mx, bounds[w + 1] - bounds[w]);
+                part_max += (double)mx, part_mean += (double)g.live.size() / nw;
             }
             pool.run_parts([&](int w) {
                 for (size_t k = bounds[w]; k < bounds[w + 1]; ++k)
@@ -772,7 +786,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         }
 
         if (std::getenv("HYAS_TRACE"))
-            fprintf(stderr, "hyas rounds (%d groups): host push+pop %.3f s, launch %.3f s, wait %.3f s\n", ng, t_host, t_launch, t_wait);
+            fprintf(stderr, "hyas rounds (%d groups): host push+pop %.3f s, launch %.3f s, wait %.3f s; largest/mean worker share %.2f\n", ng,
+                    t_host, t_launch, t_wait, part_mean > 0 ? part_max / part_mean : 0.0);
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
