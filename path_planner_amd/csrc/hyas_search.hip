@@ -523,6 +523,9 @@ int host_threads()
 
 } // namespace
 
+// queries per group
+static size_t gcap_hint(size_t cn, int ng) { return (cn + ng - 1) / ng; }
+
 int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out)
 {
     HYAS_HIP(c, hipSetDevice(c->device));
@@ -558,7 +561,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
         const size_t o_in = take(cn * sizeof(StepIn));
-        const int ng = (int)std::min<size_t>(n_groups, cn);
+        const int ng = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_groups, cn / 32 + 1), (size_t)pool.size()));
+        const int threads_per_group = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / ng, gcap_hint(cn, ng) / 8 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
         const size_t o_succ = take(ng * res_stride(gcap));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
@@ -657,14 +661,17 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         HYAS_HIP(c, hipStreamSynchronize(c->stream));
 
 
-        // rounds.  The chunk's queries form groups that take turns: while the
-        // kernels of the other groups run, the host pushes one group's successors
-        // and pops its next nodes.
+        // rounds.  The chunk's queries form groups that advance independently: every group has its own driver
+        // thread, helper threads, stream and slice of the staging block.  While a group's kernel runs, the other
+        // groups push successors, pop their next nodes and launch; nothing is shared between groups but the map.
         struct Group
         {
             std::vector<uint32_t> live, keep;
+            std::vector<size_t> bounds;
             size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
-            bool inflight = false;
+            double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0;
+            int64_t launches = 0;
+            int rc = HYAS_OK;
         } G[HYAS_MAX_GROUPS];
         for (int gi = 0; gi < ng; ++gi)
         {
@@ -673,44 +680,34 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 G[gi].live.push_back((uint32_t)i);
         }
         std::vector<uint8_t> wants(cn);
-        std::vector<size_t> bounds;
         std::vector<StepIn> stage(cn); // next round's input of every query, filled by the worker that popped it
-        double t_host = 0, t_launch = 0, t_wait = 0, part_max = 0, part_mean = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        // each group owns a stream and a slice of the staging block, laid out for the group's current size so the
-        // results of a round come back in one copy
-        auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) -> size_t {
+        // where a group's results of the current round lie in the staging block (laid out for its current size)
+        auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
             size_t o = o_succ + (&g - G) * res_stride(gcap);
             p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
             p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
             p_ok = o, o += (g.ns + 15) & ~(size_t)15;
             p_cnt = o, o += (g.ns + 15) & ~(size_t)15;
-            return o - p_succ;
         };
         // host part of a round for one group: push the successors of the round that just finished (if any), pop
         // the next node of every query; false when all queries of the group have finished
-        auto host_round = [&](Group &g, bool have_results) -> bool {
+        auto host_round = [&](Group &g, Pool &gp, bool have_results) -> bool {
             const double t0 = now();
             size_t p_succ, p_len, p_ok, p_cnt;
-            (void)slice(g, p_succ, p_len, p_ok, p_cnt);
+            slice(g, p_succ, p_len, p_ok, p_cnt);
             const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
             const float *r_len = (const float *)(hs + p_len);
             const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
             // equal shares of the group's live queries, in index order: a query stays with the same worker from
             // round to round (its heap, cell map and duplicate hash stay in that core's cache) and only moves to a
             // neighbour when queries in front of it finish
-            const int nw = pool.size();
-            bounds.resize(nw + 1);
+            const int nw = gp.size();
+            g.bounds.resize(nw + 1);
             for (int w = 0; w <= nw; ++w)
-                bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
-            {
-                size_t mx = 0;
-                for (int w = 0; w < nw; ++w)
-                    mx = std::max(mx, bounds[w + 1] - bounds[w]);
-                part_max += (double)mx, part_mean += (double)g.live.size() / nw;
-            }
-            pool.run_parts([&](int w) {
-                for (size_t k = bounds[w]; k < bounds[w + 1]; ++k)
+                g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
+            gp.run_parts([&](int w) {
+                for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
                     if (have_results)
@@ -733,7 +730,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
             g.live.swap(g.keep); // queries that finished drop out
             g.ns = g.live.size();
-            t_host += now() - t0;
+            g.t_host += now() - t0;
             return g.ns != 0;
         };
         // One launch per round.  The kernel reads the popped nodes from, and writes its results to, the pinned
@@ -744,50 +741,66 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             const size_t s0 = g.s0, ns = g.ns;
             const double t0 = now();
             size_t p_succ, p_len, p_ok, p_cnt;
-            (void)slice(g, p_succ, p_len, p_ok, p_cnt);
+            slice(g, p_succ, p_len, p_ok, p_cnt);
             const StepIn *d_in = (const StepIn *)(hd + o_in) + s0;
             (void)hipEventRecord(ev[0], st);
             launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
                          (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
                          c->stats_mode, st);
             (void)hipEventRecord(ev[1], st);
-            HYAS_HIP(c, hipGetLastError());
-            g.inflight = true;
-            t_launch += now() - t0;
-            return HYAS_OK;
+            hipError_t e = hipGetLastError();
+            g.t_launch += now() - t0;
+            return e == hipSuccess ? HYAS_OK : HYAS_ENODEV;
         };
         auto wait = [&](Group &g, int gi) -> int {
             const double t0 = now();
-            HYAS_HIP(c, hipStreamSynchronize(c->round_stream[gi]));
-            g.inflight = false;
-            t_wait += now() - t0;
+            hipError_t e = hipStreamSynchronize(c->round_stream[gi]);
+            g.t_wait += now() - t0;
+            if (e != hipSuccess)
+                return HYAS_ENODEV;
             float ms = 0;
             if (hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
-                c->k_ms[0] += ms;
-            c->k_launches[0] += 1;
+                g.k_ms += ms;
+            g.launches += 1;
             return HYAS_OK;
         };
-        for (int gi = 0; gi < ng; ++gi)
-            if (host_round(G[gi], false) && (rc = launch(G[gi], gi)) != HYAS_OK)
-                return rc;
-        for (bool any = true; any;)
-        {
-            any = false;
-            for (int gi = 0; gi < ng; ++gi)
+        // the whole search of one group
+        auto drive = [&](int gi) {
+            Group &g = G[gi];
+            if (hipSetDevice(c->device) != hipSuccess)
             {
-                if (!G[gi].inflight)
-                    continue;
-                any = true;
-                if ((rc = wait(G[gi], gi)) != HYAS_OK)
-                    return rc;
-                if (host_round(G[gi], true) && (rc = launch(G[gi], gi)) != HYAS_OK)
-                    return rc;
+                g.rc = HYAS_ENODEV;
+                return;
             }
+            Pool gp(threads_per_group);
+            bool more = host_round(g, gp, false);
+            while (more)
+            {
+                if ((g.rc = launch(g, gi)) != HYAS_OK || (g.rc = wait(g, gi)) != HYAS_OK)
+                    return;
+                more = host_round(g, gp, true);
+            }
+        };
+        {
+            std::vector<std::thread> drivers;
+            for (int gi = 1; gi < ng; ++gi)
+                drivers.emplace_back(drive, gi);
+            drive(0);
+            for (auto &t : drivers)
+                t.join();
+        }
+        double t_host = 0, t_launch = 0, t_wait = 0;
+        for (int gi = 0; gi < ng; ++gi)
+        {
+            if (G[gi].rc != HYAS_OK)
+                return c->fail(G[gi].rc, "a HIP call failed in a search round");
+            c->k_ms[0] += G[gi].k_ms, c->k_launches[0] += G[gi].launches;
+            t_host = std::max(t_host, G[gi].t_host), t_launch = std::max(t_launch, G[gi].t_launch), t_wait = std::max(t_wait, G[gi].t_wait);
         }
 
         if (std::getenv("HYAS_TRACE"))
-            fprintf(stderr, "hyas rounds (%d groups): host push+pop %.3f s, launch %.3f s, wait %.3f s; largest/mean worker share %.2f\n", ng,
-                    t_host, t_launch, t_wait, part_mean > 0 ? part_max / part_mean : 0.0);
+            fprintf(stderr, "hyas rounds (%d groups x %d threads, slowest group): host push+pop %.3f s, launch %.3f s, wait %.3f s\n", ng,
+                    threads_per_group, t_host, t_launch, t_wait);
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
