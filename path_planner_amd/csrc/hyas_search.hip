@@ -544,7 +544,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t chunk_cap = 4096;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
-    size_t n_groups = 4; // query groups in flight at once
+    size_t n_groups = 4; // query groups in flight at once (more than the four hardware queues of a process serialise)
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
     const size_t twod = c->twod_size;
@@ -561,8 +561,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
         const size_t o_in = take(cn * sizeof(StepIn));
-        const int ng = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_groups, cn / 32 + 1), (size_t)pool.size()));
-        const int threads_per_group = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / ng, gcap_hint(cn, ng) / 8 + 1));
+        const int ng = (int)std::max<size_t>(1, std::min<size_t>(n_groups, cn / 32 + 1));
+        const int n_drivers = std::max(1, std::min(std::min(ng, 4), pool.size())); // 4 = hardware queues of a process
+        const int threads_per_driver =
+            (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
         const size_t o_succ = take(ng * res_stride(gcap));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
@@ -661,9 +663,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         HYAS_HIP(c, hipStreamSynchronize(c->stream));
 
 
-        // rounds.  The chunk's queries form groups that advance independently: every group has its own driver
-        // thread, helper threads, stream and slice of the staging block.  While a group's kernel runs, the other
-        // groups push successors, pop their next nodes and launch; nothing is shared between groups but the map.
+        // rounds.  The chunk's queries form groups that advance independently: every group has its own stream and
+        // slice of the staging block; up to four driver threads (with helper threads) each look after a share of
+        // the groups.  While a group's kernel runs, its driver pushes successors, pops the next nodes and launches
+        // for its other groups; nothing is shared between groups but the map.
         struct Group
         {
             std::vector<uint32_t> live, keep;
@@ -764,27 +767,43 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             g.launches += 1;
             return HYAS_OK;
         };
-        // the whole search of one group
-        auto drive = [&](int gi) {
-            Group &g = G[gi];
+        // One driver thread (with its helpers) takes every n_drivers-th group and keeps all of them in flight:
+        // while the kernel of one of its groups runs it does the host part of the next.
+        auto drive = [&](int d) {
             if (hipSetDevice(c->device) != hipSuccess)
             {
-                g.rc = HYAS_ENODEV;
+                G[d].rc = HYAS_ENODEV;
                 return;
             }
-            Pool gp(threads_per_group);
-            bool more = host_round(g, gp, false);
-            while (more)
+            Pool gp(threads_per_driver);
+            bool inflight[HYAS_MAX_GROUPS] = {false};
+            for (int gi = d; gi < ng; gi += n_drivers)
+                if (host_round(G[gi], gp, false))
+                {
+                    if ((G[gi].rc = launch(G[gi], gi)) != HYAS_OK)
+                        return;
+                    inflight[gi] = true;
+                }
+            for (bool any = true; any;)
             {
-                if ((g.rc = launch(g, gi)) != HYAS_OK || (g.rc = wait(g, gi)) != HYAS_OK)
-                    return;
-                more = host_round(g, gp, true);
+                any = false;
+                for (int gi = d; gi < ng; gi += n_drivers)
+                {
+                    if (!inflight[gi])
+                        continue;
+                    any = true;
+                    if ((G[gi].rc = wait(G[gi], gi)) != HYAS_OK)
+                        return;
+                    inflight[gi] = host_round(G[gi], gp, true);
+                    if (inflight[gi] && (G[gi].rc = launch(G[gi], gi)) != HYAS_OK)
+                        return;
+                }
             }
         };
         {
             std::vector<std::thread> drivers;
-            for (int gi = 1; gi < ng; ++gi)
-                drivers.emplace_back(drive, gi);
+            for (int d = 1; d < n_drivers; ++d)
+                drivers.emplace_back(drive, d);
             drive(0);
             for (auto &t : drivers)
                 t.join();
@@ -799,8 +818,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         }
 
         if (std::getenv("HYAS_TRACE"))
-            fprintf(stderr, "hyas rounds (%d groups x %d threads, slowest group): host push+pop %.3f s, launch %.3f s, wait %.3f s\n", ng,
-                    threads_per_group, t_host, t_launch, t_wait);
+            fprintf(stderr, "hyas rounds (%d groups, %d drivers x %d threads; slowest group): host push+pop %.3f s, launch %.3f s, wait %.3f s\n",
+                    ng, n_drivers, threads_per_driver, t_host, t_launch, t_wait);
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
