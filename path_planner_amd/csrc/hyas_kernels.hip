@@ -437,7 +437,7 @@ __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float
 // eight lanes of waves 2-3 the swept-segment tests and, for survivors, cost
 // and heuristic.
 // MODE 0: plain; 1: work counters (stats[3..6]).
-#define ROUND_THREADS 256
+#define ROUND_THREADS 512
 #define EXPAND_THREADS ROUND_THREADS
 #define SHOT_THREADS ROUND_THREADS
 
@@ -466,7 +466,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     __shared__ uint8_t s_pose[EXPAND_THREADS / 2];
     // eight lanes per node and test; waves 0-1 run the pose tests, waves 2-3 the swept-segment tests
     // (a wave that mixed the two would run them one after the other)
-    const int lane = tid & 63, sl = tid & 7, local = (tid & 127) >> 3;
+    const int lane = tid & 63, sl = tid & 7, local = (tid & (EXPAND_THREADS / 2 - 1)) >> 3;
     const uint32_t slot = block * (EXPAND_THREADS / 16) + local;
     const bool live = slot < n;
     const StepIn node = in[live ? slot : 0];
@@ -492,7 +492,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     if (pose_lane)
         s_pose[tid] = part_ok ? 1 : 0;
     __syncthreads();
-    const bool ok = seg_lane && evaluated && part_ok && s_pose[tid & 127] != 0;
+    const bool ok = seg_lane && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0;
     hyas_succ s;
     if (ok)
     {
@@ -595,8 +595,8 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     else
     {
         // candidate groups per wave (group = closed form x backwards?, four symmetries each)
-        const int groups[4][3] = {{0, 1, 10}, {2, 3, 9}, {4, 5, -1}, {6, 8, 7}};
-        const int g = (lane < 12) ? groups[wave][lane >> 2] : -1;
+        const int groups[8][2] = {{0, 10}, {1, -1}, {2, 3}, {4, -1}, {5, -1}, {6, 8}, {7, -1}, {9, -1}};
+        const int g = (lane < 8) ? groups[wave][lane >> 2] : -1;
         if (g >= 0)
         {
             const int c = g * 4 + (lane & 3);
