@@ -29,9 +29,12 @@ def gather_slices(local, n_slices, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local[:n_slices].contiguous()
     world = dist.get_world_size()
+    dev = local.device
+    if dist.get_backend() != "nccl" and dev.type == "cuda":
+        local = local.cpu()  # CPU rehearsal backends gather host tensors
     full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(full, local.contiguous())
-    return full[:n_slices].contiguous()
+    return full[:n_slices].to(dev).contiguous()
 
 
 def build_table_sharded(ctx, curve, dist=None, device=None):
