@@ -24,6 +24,8 @@ namespace hyas
 namespace
 {
 
+#define HYAS_MAX_SPEC 8 // most nodes of one query in one round
+
 struct SNode
 {
     float x, y, t, g, h;
@@ -110,6 +112,10 @@ struct Query
     std::vector<int32_t> dup_head; // spatial hash over the open list
     int iterations = 0, counter = 0, N = 0;
     int cur = -1, cur_idx = 0; // node being expanded this round
+    // nodes handed to the kernel this round: spec[0] = cur, the others are the open list's next best entries,
+    // expanded ahead of time in case one of them is popped right after cur
+    int32_t spec[HYAS_MAX_SPEC];
+    int nspec = 0;
     bool shoot = false;
     bool done = false;
     int shot_from = -1; // >= 0: finished through an analytic shot from this node
@@ -209,6 +215,38 @@ struct Driver
         dup_remove(q, q.heap.front().node);
         std::pop_heap(q.heap.begin(), q.heap.end(), After());
         q.heap.pop_back();
+    }
+
+    // The open list's next best entries after its top, at most `want` of them, in pop order; entries whose cell
+    // is already closed are passed over (advance() would discard them).  Does not modify the heap.
+    int next_best(Query &q, int32_t *out, int want) const
+    {
+        const std::vector<HeapItem> &h = q.heap;
+        After after;
+        size_t cand[2 * HYAS_MAX_SPEC + 4];
+        int nc = 0, got = 0;
+        if (!h.empty())
+            cand[nc++] = 0; // the current top: it is popped next if cur's successors do not beat it
+        // the heap array is a binary tree: the next smallest entry is always a child of one already taken
+        int guard = 4 * HYAS_MAX_SPEC;
+        while (nc > 0 && got < want && guard-- > 0)
+        {
+            int b = 0;
+            for (int i = 1; i < nc; ++i)
+                if (after(h[cand[b]], h[cand[i]]))
+                    b = i;
+            const size_t at = cand[b];
+            cand[b] = cand[--nc];
+            const SNode &n = q.arena[h[at].node];
+            CellMap::Slot *cell = q.cells.find(idx_3d(m, n.x, n.y, n.t));
+            if (!(cell && cell->closed))
+                out[got++] = h[at].node;
+            if (2 * at + 1 < h.size() && nc < (int)(sizeof cand / sizeof cand[0]))
+                cand[nc++] = 2 * at + 1;
+            if (2 * at + 2 < h.size() && nc < (int)(sizeof cand / sizeof cand[0]))
+                cand[nc++] = 2 * at + 2;
+        }
+        return got;
     }
 
     // ---- path assembly -----------------------------------------------------
@@ -547,6 +585,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t n_groups = 4; // query groups in flight at once (more than the four hardware queues of a process serialise)
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
+    // Nodes of one query expanded per round: its popped node plus the next best open-list entries, whose
+    // results are used only if the search pops exactly that node next (it often does on plateaus of equal cost),
+    // which saves the round trip.  The answers are those of one node per round.
+    int spec_k = 4;
+    if (const char *e = std::getenv("HYAS_SPEC"))
+        spec_k = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
+    const size_t KS = (size_t)spec_k;
     const size_t twod = c->twod_size;
     std::vector<float> shot_buf;
 
@@ -560,13 +605,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-        const size_t o_in = take(cn * sizeof(StepIn));
+        const size_t o_in = take(cn * KS * sizeof(StepIn));
         const int ng = (int)std::max<size_t>(1, std::min<size_t>(n_groups, cn / 32 + 1));
         const int n_drivers = std::max(1, std::min(std::min(ng, 4), pool.size())); // 4 = hardware queues of a process
         const int threads_per_driver =
             (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
-        const size_t o_succ = take(ng * res_stride(gcap));
+        const size_t o_succ = take(ng * res_stride(gcap * KS));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
         const size_t o_twod_host = take(cn * twod * sizeof(float));
         int rc = ensure_scratch(c, o_twod_host, off);
@@ -683,11 +728,14 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 G[gi].live.push_back((uint32_t)i);
         }
         std::vector<uint8_t> wants(cn);
-        std::vector<StepIn> stage(cn); // next round's input of every query, filled by the worker that popped it
+        std::vector<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
+        std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
+        const bool P_analytic = c->P.analytical_expansion != 0;
+        std::atomic<uint64_t> spec_hits{0};
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // where a group's results of the current round lie in the staging block (laid out for its current size)
         auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
-            size_t o = o_succ + (&g - G) * res_stride(gcap);
+            size_t o = o_succ + (&g - G) * res_stride(gcap * KS);
             p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
             p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
             p_ok = o, o += (g.ns + 15) & ~(size_t)15;
@@ -710,29 +758,65 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             for (int w = 0; w <= nw; ++w)
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             gp.run_parts([&](int w) {
+                uint64_t hits = 0;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
-                    if (have_results)
-                        D.consume(q, r_ok[k], r_len[k], r_cnt[k], r_succ + k * K);
                     const uint32_t qi = g.live[k];
-                    wants[qi] = (!q.done && D.advance(q)) ? 1 : 0;
-                    if (wants[qi])
+                    bool want;
+                    if (have_results)
                     {
-                        const SNode &nd = q.arena[q.cur]; // still in this worker's cache
-                        stage[qi] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, q.shoot ? 1u : 0u, 0};
+                        int at = 0; // which of the query's nodes of the last launch is being consumed
+                        for (;;)
+                        {
+                            const size_t sl = slot0[qi] + at;
+                            D.consume(q, r_ok[sl], r_len[sl], r_cnt[sl], r_succ + sl * K);
+                            want = !q.done && D.advance(q);
+                            if (!want)
+                                break;
+                            // the node popped now: was it expanded ahead of time?
+                            int j = -1;
+                            for (int i = 1; i < q.nspec; ++i)
+                                if (q.spec[i] == q.cur)
+                                    j = i;
+                            if (j < 0)
+                                break; // no: it goes to the GPU
+                            at = j;
+                            ++hits;
+                        }
+                    }
+                    else
+                        want = !q.done && D.advance(q);
+                    wants[qi] = want ? 1 : 0;
+                    if (want)
+                    {
+                        q.spec[0] = q.cur;
+                        q.nspec = 1 + (spec_k > 1 ? D.next_best(q, q.spec + 1, spec_k - 1) : 0);
+                        for (int i = 0; i < q.nspec; ++i)
+                        {
+                            const SNode &nd = q.arena[q.spec[i]];
+                            // a node expanded ahead of time always gets its shot evaluated: whether the search will
+                            // ask for it is only known when the node is popped
+                            const uint32_t shoot = i == 0 ? (q.shoot ? 1u : 0u) : (P_analytic ? 1u : 0u);
+                            stage[qi * KS + i] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, shoot, 0};
+                        }
                     }
                 }
+                if (hits)
+                    spec_hits.fetch_add(hits, std::memory_order_relaxed);
             });
             g.keep.clear();
+            size_t slots = 0;
             for (uint32_t qi : g.live)
                 if (wants[qi])
                 {
-                    h_in[g.s0 + g.keep.size()] = stage[qi];
+                    slot0[qi] = (uint32_t)slots;
+                    for (int i = 0; i < Q[qi].nspec; ++i)
+                        h_in[g.s0 * KS + slots++] = stage[qi * KS + i];
                     g.keep.push_back(qi);
                 }
             g.live.swap(g.keep); // queries that finished drop out
-            g.ns = g.live.size();
+            g.ns = slots;
             g.t_host += now() - t0;
             return g.ns != 0;
         };
@@ -745,7 +829,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             const double t0 = now();
             size_t p_succ, p_len, p_ok, p_cnt;
             slice(g, p_succ, p_len, p_ok, p_cnt);
-            const StepIn *d_in = (const StepIn *)(hd + o_in) + s0;
+            const StepIn *d_in = (const StepIn *)(hd + o_in) + s0 * KS;
             (void)hipEventRecord(ev[0], st);
             launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
                          (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
@@ -818,8 +902,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         }
 
         if (std::getenv("HYAS_TRACE"))
-            fprintf(stderr, "hyas rounds (%d groups, %d drivers x %d threads; slowest group): host push+pop %.3f s, launch %.3f s, wait %.3f s\n",
-                    ng, n_drivers, threads_per_driver, t_host, t_launch, t_wait);
+            fprintf(stderr,
+                    "hyas rounds (%d groups, %d drivers x %d threads, %d nodes per query; slowest group): host push+pop %.3f s, launch %.3f s, "
+                    "wait %.3f s; %llu expansions answered ahead of time\n",
+                    ng, n_drivers, threads_per_driver, spec_k, t_host, t_launch, t_wait, (unsigned long long)spec_hits.load());
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
