@@ -582,7 +582,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t chunk_cap = 4096;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
-    size_t n_groups = 4; // query groups in flight at once (more than the four hardware queues of a process serialise)
+    size_t n_groups = 8; // query groups in flight at once: two per driver thread and hardware queue, so a driver
+                         // does the host part of one group while the kernel of its other group runs
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
     // Nodes of one query expanded per round: its popped node plus the next best open-list entries, whose
