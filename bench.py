@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the Hybrid A* expansion path on MI355X.
 
-Workload (BASELINE.json configs[1]): maps/map_maze.png (50x50 cells, 1 m), a
+Workload: maps/map_maze.png (50x50 cells, 1 m), a
 batch of 1024 random start/goal queries, Reeds-Shepp shot evaluated at every
 popped node, reference struct-default parameters with 5 forward + 1 reverse
 primitive.  One "step" = one hyas_plan_batch over the whole batch.  At N GPUs
 every rank plans its own 1024 queries (weak scaling, no data-path collective).
+Every round the search sends each query's popped node and its next best open
+nodes to the GPU and uses a result only for the node it pops next, so the
+answers are those of expanding one node at a time.
 
 Prints ONE JSON line on rank 0.  `value` = successors that received a full
 collision verdict + g + h, per second, summed over ranks; the map, tables and
@@ -157,7 +160,9 @@ def main():
                     "traffic": traffic, "kernel": "k_round", "avg_launch_us": avg_ms * 1e3,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": launches_1,
                     "note": "map, obstacle lists and tables are <= 30 MB and cache-resident: HBM fraction is low by "
-                            "construction; the kernel is bound by f32/f64 ALU and L2/L1 latency"}
+                            "construction; a launch lasts as long as its slowest workgroup's dependent chain (solve, reduce, "
+                            "interpolate, list walk). Bytes count every node a launch processed, including nodes expanded ahead "
+                            "of time; `value` counts only expansions the search consumed"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(map_arr, starts, goals)
 
