@@ -579,7 +579,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
 
     // Queries are processed in chunks so the per-query 2D cost maps of one
     // chunk fit a fixed device buffer.
-    size_t chunk_cap = 4096;
+    size_t chunk_cap = 8192;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
     size_t n_groups = 8; // query groups in flight at once: two per driver thread and hardware queue, so a driver
