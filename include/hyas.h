@@ -216,8 +216,10 @@ int hyas_get_path(const hyas_ctx *ctx, size_t i, float *xyt, size_t cap);
 int hyas_get_expanded(const hyas_ctx *ctx, size_t i, int32_t *idx, size_t cap);
 
 /* Time in milliseconds the GPU spent in each kernel family during the last
- * hyas_plan_batch / *_batch call, measured with HIP events on the context's
- * stream.  which: 0 shot, 1 expand, 2 collision, 3 table, 4 flood/other. */
+ * hyas_plan_batch / *_batch call, measured with HIP events on the streams the
+ * kernels were launched on, summed over launches; *launches receives their
+ * number.  which: 0 search round (hyas_plan_batch) or shot (hyas_shot_batch),
+ * 1 successors (hyas_expand_batch), 2 collision batch, 3 table build, 4 unused. */
 double hyas_last_kernel_ms(const hyas_ctx *ctx, int which, int64_t *launches);
 void hyas_reset_kernel_timers(hyas_ctx *ctx);
 
