@@ -144,3 +144,23 @@ def test_large_map_query_blocks(oracle_built):
         r, path, exp = o.plan(S[i], G[i])
         assert r.tobytes() == whole[i].tobytes(), i
         assert np.array_equal(exp, keep[i][1]) and path.tobytes() == keep[i][0].tobytes()
+
+
+def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
+    """How the host schedules the search (query groups in flight, worker threads, nodes expanded ahead of time per
+    query, chunk size) must not show in any output: result records, expansion order and paths are bit-identical."""
+    h = maze_ctx
+    S, G = make_queries(h.collision, 300, 77, 50, 50)
+    base = h.plan_batch(S, G)
+    keep = [(h.path(i), h.expanded(i)) for i in range(300)]
+    assert base["nodes_expanded"].sum() > 100000
+    for env in (dict(HYAS_SPEC="1", HYAS_GROUPS="1", HYAS_THREADS="1"), dict(HYAS_SPEC="2", HYAS_GROUPS="3", HYAS_THREADS="5"),
+                dict(HYAS_SPEC="8", HYAS_GROUPS="8", HYAS_THREADS="16"), dict(HYAS_SPEC="4", HYAS_CHUNK="97")):
+        for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res = h.plan_batch(S, G)
+        assert res.tobytes() == base.tobytes(), env
+        for i in range(0, 300, 7):
+            assert np.array_equal(h.path(i), keep[i][0]) and np.array_equal(h.expanded(i), keep[i][1]), (env, i)
