@@ -589,10 +589,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // Nodes of one query expanded per round: its popped node plus the next best open-list entries, whose
     // results are used only if the search pops exactly that node next (it often does on plateaus of equal cost),
     // which saves the round trip.  The answers are those of one node per round.
-    int spec_k = 4;
+    // Wider pays while a group's launch is short: 6 for groups of up to 256 queries, else 4.
+    int spec_cfg = 0; // 0 = choose per chunk
     if (const char *e = std::getenv("HYAS_SPEC"))
-        spec_k = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
-    const size_t KS = (size_t)spec_k;
+        spec_cfg = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
     const size_t twod = c->twod_size;
     std::vector<float> shot_buf;
 
@@ -606,12 +606,17 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-        const size_t o_in = take(cn * KS * sizeof(StepIn));
         const int ng = (int)std::max<size_t>(1, std::min<size_t>(n_groups, cn / 32 + 1));
-        const int n_drivers = std::max(1, std::min(std::min(ng, 4), pool.size())); // 4 = hardware queues of a process
+        const size_t gcap = (cn + ng - 1) / ng; // queries per group
+        const int spec_k = spec_cfg ? spec_cfg : (gcap <= 256 ? 6 : 4);
+        const size_t KS = (size_t)spec_k;
+        const size_t o_in = take(cn * KS * sizeof(StepIn));
+        int max_drivers = 4; // 4 = hardware queues of a process
+        if (const char *e = std::getenv("HYAS_DRIVERS"))
+            max_drivers = std::max(1, std::atoi(e));
+        const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
         const int threads_per_driver =
             (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
-        const size_t gcap = (cn + ng - 1) / ng; // queries per group
         const size_t o_succ = take(ng * res_stride(gcap * KS));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
         const size_t o_twod_host = take(cn * twod * sizeof(float));
