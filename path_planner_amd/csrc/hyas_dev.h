@@ -222,14 +222,16 @@ HD int above_segment(F2 p1, F2 p2, F2 p3)
 }
 
 // src/utility.cpp:375-422: ray casting towards (10000, p.y)
-HDC bool inside_quad(Quad q, F2 p)
+// (out-of-line routines take the vertices one by one: a 64-byte Quad by value would travel through the stack)
+HDC bool inside_verts(F2 q0, F2 q1, F2 q2, F2 q3, F2 p)
 {
+    const F2 v[4] = {q0, q1, q2, q3};
     F2 far_pt = f2(10000, p.y);
     int crossings = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        F2 a = qv(q, i), b = qv(q, i + 1);
+        F2 a = v[i], b = v[(i + 1) & 3];
         if (seg_intersect(p, far_pt, a, b))
         {
             F2 ip = intersection_point(p, far_pt, a, b);
@@ -243,6 +245,7 @@ HDC bool inside_quad(Quad q, F2 p)
     }
     return (crossings & 1) != 0;
 }
+HD bool inside_quad(const Quad &q, F2 p) { return inside_verts(qv(q, 0), qv(q, 1), qv(q, 2), qv(q, 3), p); }
 
 // src/utility.cpp:1591-1596: Eigen normalized()
 HD F2 unit_vector(F2 a, F2 b)
@@ -405,19 +408,24 @@ struct GlobalQuads
 // src/utility.cpp:956-966 + :528-540 for a 4-corner vehicle against one quad.
 // The bounding-box test is exact: when the boxes are strictly apart every
 // edge pair fails IsIntersect's own box test.
-HDC bool vehicle_hits_quad(F2 c0, F2 c1, F2 c2, F2 c3, Quad q)
+HDC bool vehicle_hits_verts(F2 c0, F2 c1, F2 c2, F2 c3, F2 q0, F2 q1, F2 q2, F2 q3)
 {
     const F2 c[4] = {c0, c1, c2, c3};
+    const F2 v[4] = {q0, q1, q2, q3};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
         const F2 a = c[i], b = c[(i + 1) & 3];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (seg_intersect(qv(q, j), qv(q, j + 1), a, b))
+            if (seg_intersect(v[j], v[(j + 1) & 3], a, b))
                 return true;
     }
     return false;
+}
+HD bool vehicle_hits_quad(F2 c0, F2 c1, F2 c2, F2 c3, const Quad &q)
+{
+    return vehicle_hits_verts(c0, c1, c2, c3, qv(q, 0), qv(q, 1), qv(q, 2), qv(q, 3));
 }
 
 // src/collisiondetection.cpp:189-214 + :573-606.  true = free.
@@ -507,12 +515,13 @@ HD bool near_box(F2 p, F2 a, F2 b, float r)
     return !(p.x < fminf_(a.x, b.x) - r || p.x > fmaxf_(a.x, b.x) + r || p.y < fminf_(a.y, b.y) - r || p.y > fmaxf_(a.y, b.y) + r);
 }
 // the edge part: the quad's box is within r of the segment's box
-HDC bool seg_hits_quad_near(float r, double half_wid, F2 s, F2 e, Quad q)
+HDC bool seg_hits_verts_near(float r, double half_wid, F2 s, F2 e, F2 q0, F2 q1, F2 q2, F2 q3)
 {
+    const F2 v[4] = {q0, q1, q2, q3};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        const F2 a = qv(q, i), b = qv(q, i + 1);
+        const F2 a = v[i], b = v[(i + 1) & 3];
         if (seg_intersect(a, b, s, e))
             return true;
         if (near_box(s, a, b, r) && (double)dist_seg_point(a, b, s) <= half_wid)
@@ -549,7 +558,7 @@ HD bool seg_hits_quad(float r, double half_wid, F2 s, F2 e, const Quad &q)
     const float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
     if (q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin)
         return false;
-    return seg_hits_quad_near(r, half_wid, s, e, q);
+    return seg_hits_verts_near(r, half_wid, s, e, qv(q, 0), qv(q, 1), qv(q, 2), qv(q, 3));
 }
 
 // src/collisiondetection.cpp:608-656.  true = free.

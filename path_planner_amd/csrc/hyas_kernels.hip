@@ -653,14 +653,13 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     }
 
     // ---- phase 3 ------------------------------------------------------------
-    rs::Path path;
+    const rs::Path &path = s_path; // read in place: a private copy indexed by segment would live in scratch memory
     db::Path dpath;
     const double rho = (double)m.shot_rho;
     double length;
     uint32_t nsamp;
     if (RS)
     {
-        path = s_path;
         length = rho * path.total; // src/ReedsShepp.cpp:564
         nsamp = count_samples(seg_tab, seg_cap, length);
     }

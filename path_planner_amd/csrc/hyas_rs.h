@@ -69,7 +69,13 @@ RS_HD void tau_omega(double u, double v, double xi, double eta, double phi, doub
 }
 
 // The eight base formulas, :73-108, :160-175, :229-260, :312-345, :449-467.
-RS_HDC bool base_formula(int f, double x, double y, double phi, double &t, double &u, double &v)
+// (out of line; the result travels by value: reference parameters would live on the stack)
+struct TUV
+{
+    double t, u, v;
+    int ok;
+};
+RS_HD bool base_formula_body(int f, double x, double y, double phi, double &t, double &u, double &v)
 {
     const double sp = hy_sin(phi), cp = hy_cos(phi);
     switch (f)
@@ -184,6 +190,20 @@ RS_HDC bool base_formula(int f, double x, double y, double phi, double &t, doubl
     }
 }
 
+RS_HDC TUV base_formula_call(int f, double x, double y, double phi)
+{
+    TUV r;
+    r.t = r.u = r.v = 0;
+    r.ok = base_formula_body(f, x, y, phi, r.t, r.u, r.v) ? 1 : 0;
+    return r;
+}
+RS_HD bool base_formula(int f, double x, double y, double phi, double &t, double &u, double &v)
+{
+    const TUV r = base_formula_call(f, x, y, phi);
+    t = r.t, u = r.u, v = r.v;
+    return r.ok != 0;
+}
+
 // Candidate list in reference order.  Groups of four share a base formula and
 // run through the symmetries (x,y,phi), (-x,y,-phi) "timeflip", (x,-y,-phi)
 // "reflect", (-x,-y,phi) both.  group: base formula, uses backwards frame?,
@@ -211,7 +231,7 @@ RS_HD int family_first(int fam)
 // Evaluates candidate c for the normalised goal (x, y, phi).  On success fills
 // p (word, signed lengths, total) and L, the length the family compares
 // (|t|+|u|+|v|, with 2|u| in the CCCC family).
-RS_HDC bool candidate(int c, double x, double y, double phi, Path &p, double &L)
+RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
 {
     int formula, backwards, family, word, layout;
     group_info(c >> 2, formula, backwards, family, word, layout);
