@@ -1,0 +1,17 @@
+#!/bin/bash
+# The round's measurement set, run on the GPU box from the repository root:  bash profiles/collect_all.sh r01
+#  1. bench.py (headline line)               -> gpurun_out/meas/bench_line.json
+#  2. the same command under rocprofv3 stats -> gpurun_out/meas/kernel_stats.csv
+#  3. HBM-side traffic counter passes        -> gpurun_out/pmc/step_kernel_traffic.json
+# Copy the results into profiles/<round>_* afterwards (profiles/install_results.sh does that).
+set -e
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out/meas
+timeout -k 10 400 python3 -u bench.py > gpurun_out/meas/bench_line.json
+echo "bench done"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/meas/prof -o bench --output-format csv -- python3 bench.py > gpurun_out/meas/bench_under_rocprof.json 2> gpurun_out/meas/rocprof.log
+cp gpurun_out/meas/prof/bench_kernel_stats.csv gpurun_out/meas/kernel_stats.csv
+rm -rf gpurun_out/meas/prof
+echo "kernel stats done"
+bash profiles/collect_traffic.sh
