@@ -395,7 +395,9 @@ template <typename T>
 static int upload(hyas_ctx *c, T *&dst, const std::vector<T> &src, size_t min_elems = 1)
 {
     size_t n = std::max(src.size(), min_elems);
-    HYAS_HIP(c, hipMalloc((void **)&dst, n * sizeof(T)));
+    const size_t slack = 64; // kernels fetch list entries in 16-byte blocks, one block ahead
+    HYAS_HIP(c, hipMalloc((void **)&dst, n * sizeof(T) + slack));
+    HYAS_HIP(c, hipMemset((char *)dst + src.size() * sizeof(T), 0, n * sizeof(T) + slack - src.size() * sizeof(T)));
     if (!src.empty())
         HYAS_HIP(c, hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return HYAS_OK;

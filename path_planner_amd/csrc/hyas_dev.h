@@ -397,12 +397,19 @@ HD void vehicle_corners(const DevMap &m, float x, float y, float t, F2 c[4])
 // geometry routines below work on registers, not on pointers.
 // stop() lets a caller whose overall answer is already decided (another lane
 // found a collision) cut the list walks short; hit() announces a collision.
+// Cursor hands out the entries idx[k] of one obstacle list for k = begin, begin + 1, ...
 struct GlobalQuads
 {
     const Quad *p;
     HD Quad operator()(uint32_t i) const { return p[i]; }
     HD bool stop() const { return false; }
     HD void hit() const {}
+    struct Cursor
+    {
+        const uint16_t *idx;
+        HD Cursor(const uint16_t *i, uint32_t) : idx(i) {}
+        HD uint16_t at(uint32_t k) { return idx[k]; }
+    };
 };
 
 // src/utility.cpp:956-966 + :528-540 for a 4-corner vehicle against one quad.
@@ -453,12 +460,14 @@ HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float
         return true; // key absent from in_range_obstacle_map_: nothing to test
     const uint32_t *off = m.seg_lmax > 0 ? m.pose_off : m.cell_off;
     const uint16_t *idx = m.seg_lmax > 0 ? m.pose_idx : m.cell_idx;
+    const uint32_t begin = off[key], e = off[key + 1];
+    typename QuadSrc::Cursor cur(idx, begin);
 #pragma unroll 1
-    for (uint32_t k = off[key], e = off[key + 1]; k < e; ++k)
+    for (uint32_t k = begin; k < e; ++k)
     {
         if (quads.stop())
             return true; // the caller no longer needs this verdict
-        const Quad q = quads(idx[k]);
+        const Quad q = quads(cur.at(k));
         if (q.xmax < bxmin || q.ymax < bymin || bxmax < q.xmin || bymax < q.ymin)
             continue;
         if (vehicle_hits_quad(c[0], c[1], c[2], c[3], q))
@@ -580,12 +589,14 @@ HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, 
         const uint32_t key = pass ? ke : ks;
         if (key >= cells || (pass && ke == ks)) // same key: same list, same verdicts
             continue;
+        const uint32_t begin = off[key], end = off[key + 1];
+        typename QuadSrc::Cursor cur(idx, begin);
 #pragma unroll 1
-        for (uint32_t k = off[key], end = off[key + 1]; k < end; ++k)
+        for (uint32_t k = begin; k < end; ++k)
         {
             if (quads.stop())
                 return true; // the caller no longer needs this verdict
-            const uint16_t ent = idx[k];
+            const uint16_t ent = cur.at(k);
             const Quad q = quads(ent & 0x7fffu);
             // bit 15 (pruned lists only): only the ray-casting test can fire
             if ((pruned && (ent & 0x8000u)) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad(r, m.half_wid, s, e, q))

@@ -318,19 +318,63 @@ __device__ __forceinline__ uint32_t count_samples_db(const float *__restrict__ s
 
 #define STEP_LDS_QUADS 192 // obstacle quads kept in LDS (12 KB)
 
-// Quads from the workgroup's LDS copy when there is one, else from global memory.
+// Quads from the workgroup's LDS copy when there is one, else from global memory.  The LDS pointers carry their
+// address space: through generic pointers every access would be a flat load that waits for both memory counters.
+#define HYAS_LDS __attribute__((address_space(3)))
 struct StepQuads
 {
-    const Quad *lds; // null: no local copy
+    const HYAS_LDS Quad *lds; // valid when local
     const Quad *glb;
-    volatile int *flag; // workgroup flag "a sample of this shot collides" (null: every verdict is wanted)
-    __device__ __forceinline__ Quad operator()(uint32_t i) const { return lds ? lds[i] : glb[i]; }
-    __device__ __forceinline__ bool stop() const { return flag && *flag != 0; }
+    volatile HYAS_LDS int *flag; // workgroup flag "a sample of this shot collides"
+    bool local, flagged;         // flagged == false: every verdict is wanted
+    __device__ __forceinline__ Quad operator()(uint32_t i) const
+    {
+        if (!local)
+            return glb[i];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const HYAS_LDS u32x4 *p = (const HYAS_LDS u32x4 *)(lds + i);
+        const u32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+        Quad q;
+        q.vx[0] = __uint_as_float(a.x), q.vx[1] = __uint_as_float(a.y), q.vx[2] = __uint_as_float(a.z), q.vx[3] = __uint_as_float(a.w);
+        q.vy[0] = __uint_as_float(b.x), q.vy[1] = __uint_as_float(b.y), q.vy[2] = __uint_as_float(b.z), q.vy[3] = __uint_as_float(b.w);
+        q.xmin = __uint_as_float(c.x), q.ymin = __uint_as_float(c.y), q.xmax = __uint_as_float(c.z), q.ymax = __uint_as_float(c.w);
+        q.axis_rect = d.x, q.pad[0] = q.pad[1] = q.pad[2] = 0;
+        return q;
+    }
+    __device__ __forceinline__ bool stop() const { return flagged && *flag != 0; }
     __device__ __forceinline__ void hit() const
     {
-        if (flag)
+        if (flagged)
             *flag = 1;
     }
+    // Eight list entries per 16-byte load, the following eight requested one block ahead, so that a walk waits for
+    // memory once per list and not once per entry.  Reads up to 32 bytes past the last entry: the index arrays are
+    // allocated with that much slack and start on a 16-byte boundary.
+    struct Cursor
+    {
+        const uint4 *base;
+        uint4 cur, nxt;
+        uint32_t blk;
+        __device__ __forceinline__ Cursor(const uint16_t *idx, uint32_t begin) : base(reinterpret_cast<const uint4 *>(idx)), blk(begin >> 3)
+        {
+            cur = base[blk];
+            nxt = base[blk + 1];
+        }
+        __device__ __forceinline__ uint16_t at(uint32_t k)
+        {
+            const uint32_t b = k >> 3;
+            if (b != blk)
+            {
+                cur = nxt;
+                nxt = base[b + 1];
+                blk = b;
+            }
+            const uint32_t j = k & 7u;
+            const uint32_t lo = (j & 2u) ? cur.y : cur.x, hi = (j & 2u) ? cur.w : cur.z;
+            const uint32_t word = (j & 4u) ? hi : lo;
+            return (uint16_t)((j & 1u) ? (word >> 16) : (word & 0xffffu));
+        }
+    };
 };
 #ifndef STEP_MIN_WAVES
 #define STEP_MIN_WAVES 4 // waves per SIMD the register allocation must allow: three workgroups per CU
@@ -343,64 +387,28 @@ struct CandOut
     int valid;
 };
 
-// Reduces the 44 evaluated candidates (one per lane, lanes >= 44 invalid) in
-// reference order; every lane returns the winning path.
-__device__ __forceinline__ rs::Path reduce_candidates(const rs::Path &mine, double L, bool valid, int lane)
+// rs::build_prefix with the sines and cosines of the six headings given (sn[i], cs[i] in front of segment i).
+__device__ __forceinline__ void prefix_from_sincos(const rs::Path &path, double phi0, const double *sn, const double *cs, rs::Prefix &P)
 {
-    const double inf = __builtin_huge_val();
-    rs::Path best = rs::empty_path();
-    for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
-    {
-        const bool in_fam = lane >= rs::family_first(fam) && lane < rs::family_first(fam + 1);
-        const double key = (valid && in_fam && L == L) ? L : inf;
-        const double mn = wave_min(key);
-        const double bound = rs::family_bound(fam, best.total);
-        if (bound > mn) // uniform across the wave
-        {
-            unsigned long long who = __ballot(key == mn);
-            int src = __ffsll((long long)who) - 1;
-            best.type = __shfl(mine.type, src, 64);
-            for (int i = 0; i < 5; ++i)
-                best.len[i] = __shfl(mine.len[i], src, 64);
-            best.total = __shfl(mine.total, src, 64);
-        }
-    }
-    return best;
-}
-
-// rs::build_prefix with the six heading sin/cos pairs evaluated on six lanes.
-// Every lane of the wave must call it; every lane returns the full prefix.
-__device__ __forceinline__ void build_prefix_wave(const rs::Path &path, double phi0, int lane, rs::Prefix &P)
-{
-    double phi[6];
-    phi[0] = phi0;
-    for (int i = 0; i < 5; ++i)
-    {
-        const int kind = rs::seg_kind(path.type, i);
-        phi[i + 1] = (kind == 1) ? phi[i] + path.len[i] : (kind == 3) ? phi[i] - path.len[i] : phi[i];
-    }
-    double my_phi = phi[0];
-    for (int i = 1; i < 6; ++i)
-        my_phi = (lane == i) ? phi[i] : my_phi;
-    const double my_s = hy_sin(my_phi), my_c = hy_cos(my_phi);
-    double sn[6], cs[6];
-    for (int i = 0; i < 6; ++i)
-        sn[i] = __shfl(my_s, i, 64), cs[i] = __shfl(my_c, i, 64);
+    double phi = phi0;
     P.x[0] = 0.0, P.y[0] = 0.0;
     for (int i = 0; i < 5; ++i)
     {
         const int kind = rs::seg_kind(path.type, i);
         const double v = path.len[i];
         double x = P.x[i], y = P.y[i];
+        P.phi[i] = phi, P.s[i] = sn[i], P.c[i] = cs[i];
         if (kind == 1)
         {
             x += (sn[i + 1] - sn[i]);
             y += (-cs[i + 1] + cs[i]);
+            phi = phi + v;
         }
         else if (kind == 3)
         {
             x += (-sn[i + 1] + sn[i]);
             y += (cs[i + 1] - cs[i]);
+            phi = phi - v;
         }
         else if (kind == 2)
         {
@@ -408,9 +416,8 @@ __device__ __forceinline__ void build_prefix_wave(const rs::Path &path, double p
             y += (v * sn[i]);
         }
         P.x[i + 1] = x, P.y[i + 1] = y;
-        P.phi[i] = phi[i], P.s[i] = sn[i], P.c[i] = cs[i];
     }
-    P.phi[5] = phi[5];
+    P.phi[5] = phi;
 }
 
 // Obstacle-list entries the reference walks for one (pose, predecessor) pair:
@@ -454,7 +461,7 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
         for (uint32_t i = tid; i < m.n_quads * 16u; i += ROUND_THREADS)
             dst[i] = src[i];
     }
-    return StepQuads{quads_local ? s_quads : nullptr, m.quads, nullptr};
+    return StepQuads{(const HYAS_LDS Quad *)s_quads, m.quads, nullptr, quads_local, false};
 }
 
 template <int MODE>
@@ -559,6 +566,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     __shared__ float s_xyt[SHOT_THREADS + 1][3]; // [0] = the sample in front of this batch
     __shared__ volatile int s_hit;
     __shared__ unsigned int s_first, s_lists;
+    __shared__ double s_sn[6], s_cs[6]; // sin / cos of the heading in front of segment i (5: behind the last)
     constexpr bool RS = CURVE == HYAS_CURVE_RS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StepIn node = in[slot];
@@ -569,14 +577,23 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         return;
     }
     constexpr bool STATS = MODE == 1, CLOCKS = MODE == 2;
-    long long c0 = 0, c1 = 0, c2 = 0;
+    // clock sums are kept in registers and added to stats[] once, at the end: atomics inside the phases would be
+    // waited for at the next barrier and lengthen what they measure
+    long long c0 = 0, c1 = 0, c2 = 0, t_wave = 0, t_solve = 0, t_interp = 0, t_collide = 0, t_load = 0, t_test = 0;
+    unsigned n_batches = 0;
     if (CLOCKS)
         c0 = clock64();
     const hyas_goal goal = goals[node.query];
     const double q0[3] = {(double)node.x, (double)node.y, (double)node.t};
+    if (CLOCKS)
+    {
+        // the node comes from host memory, the goal from device memory: time until both have arrived
+        if (__float_as_uint(goal.x) + __float_as_uint(node.x) != 0x12345u)
+            t_load = clock64() - c0;
+    }
     StepQuads sq = stage_quads(m, s_quads, tid); // visible after the barrier that ends phase 1
-    if (!STATS)
-        sq.flag = &s_hit; // one colliding sample decides the shot: the other lanes stop walking their lists
+    if (!STATS) // one colliding sample decides the shot: the other lanes stop walking their lists
+        sq.flag = (volatile HYAS_LDS int *)&s_hit, sq.flagged = true;
 
     // ---- phase 1 ------------------------------------------------------------
     if (!RS)
@@ -614,42 +631,59 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             s_hit = 0;
     }
     if (CLOCKS)
-    {
-        long long cw = clock64();
-        if (lane == 0)
-            atomicAdd(&stats[11 + wave], (unsigned long long)(cw - c0)); // per-wave phase-1 time
-    }
+        t_wave = clock64() - c0; // per-wave phase-1 time
     __syncthreads();
 
     // ---- phase 2 ------------------------------------------------------------
-    if (RS && wave == 0)
+    // Waves 0 and 1 both walk the 44 results in reference order (broadcast LDS reads: far shorter than reducing
+    // across lanes) and derive the heading in front of every segment; six lanes of wave 0 take the sines of the six
+    // headings, six lanes of wave 1 the cosines; thread 0 then accumulates the per-segment prefix states.
+    rs::Path best = rs::empty_path();
+    if (RS && wave < 2)
     {
-        rs::Path mine = rs::empty_path();
-        double L = 0;
-        bool valid = false;
-        if (lane < RS_NUM_CANDIDATES)
+        int win = -1;
+        double best_total = best.total;
+        for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
         {
-            const CandOut &o = s_cand[lane];
-            valid = o.valid != 0;
-            mine = o.p;
-            L = o.L;
+            double lmin = rs::family_bound(fam, best_total);
+            for (int c = rs::family_first(fam); c < rs::family_first(fam + 1); ++c)
+            {
+                const CandOut &o = s_cand[c];
+                if (o.valid != 0 && lmin > o.L)
+                    win = c, lmin = o.L, best_total = o.p.total;
+            }
         }
-        rs::Path best = reduce_candidates(mine, L, valid, lane);
+        if (win >= 0)
+            best = s_cand[win].p;
+        double my_phi = q0[2], phi = q0[2];
+        for (int i = 0; i < 5; ++i)
+        {
+            const int kind = rs::seg_kind(best.type, i);
+            phi = (kind == 1) ? phi + best.len[i] : (kind == 3) ? phi - best.len[i] : phi;
+            my_phi = (lane == i + 1) ? phi : my_phi;
+        }
+        if (lane < 6)
+        {
+            if (wave == 0)
+                s_sn[lane] = hy_sin(my_phi);
+            else
+                s_cs[lane] = hy_cos(my_phi);
+        }
+    }
+    __syncthreads();
+    if (RS && tid == 0)
+    {
         rs::Prefix pf;
-        build_prefix_wave(best, q0[2], lane, pf);
-        if (lane == 0)
-        {
-            s_path = best;
-            s_prefix = pf;
-            s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t; // predecessor of sample 0: the node
-        }
+        prefix_from_sincos(best, q0[2], s_sn, s_cs, pf);
+        s_path = best;
+        s_prefix = pf;
+        s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t; // predecessor of sample 0: the node
     }
     __syncthreads();
     if (CLOCKS)
     {
         c1 = clock64();
-        if (tid == 0)
-            atomicAdd(&stats[8], (unsigned long long)(c1 - c0)), atomicAdd(&stats[6], 1ull);
+        t_solve = c1 - c0;
     }
 
     // ---- phase 3 ------------------------------------------------------------
@@ -706,10 +740,10 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         if (CLOCKS)
         {
             c2 = clock64();
-            if (tid == 0)
-                atomicAdd(&stats[9], (unsigned long long)(c2 - c1)), atomicAdd(&stats[19], 1ull);
+            t_interp += c2 - c1, ++n_batches;
         }
-        // two test rounds: the first half of the workgroup runs the pose tests, the second half the swept-segment tests
+        // two test rounds: the first half of the workgroup runs the pose tests, the second half the swept-segment tests;
+        // the workgroup meets once, after both (in between, the flag alone tells a lane that the shot is decided)
         for (int half = 0; half < 2; ++half)
         {
             const uint32_t j = half * (SHOT_THREADS / 2) + (tid & (SHOT_THREADS / 2 - 1)); // sample inside the batch
@@ -724,7 +758,10 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             bool hit = false;
             const float x = s_xyt[j + 1][0], y = s_xyt[j + 1][1], t = s_xyt[j + 1][2];
             const float px = s_xyt[j][0], py = s_xyt[j][1];
-            if (k < nsamp)
+            long long tt = 0;
+            if (CLOCKS)
+                tt = clock64();
+            if (k < nsamp && (STATS || s_hit == 0))
             {
                 if (pose_lane)
                     hit = !(on_grid(m, x, y) && pose_free(m, sq, x, y, t));
@@ -732,13 +769,15 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                     hit = !segment_free(m, sq, x, y, px, py);
                 tested += pose_lane;
             }
+            if (CLOCKS)
+                t_test += clock64() - tt; // this wave's tests without the wait for the other waves
             if (hit)
                 s_hit = 1;
-            if (STATS && hit)
-                atomicMin(&s_first, k);
-            __syncthreads();
             if (STATS)
             {
+                if (hit)
+                    atomicMin(&s_first, k);
+                __syncthreads();
                 const uint32_t first = s_first;
                 if (k < nsamp && k <= first && pose_lane)
                     atomicAdd(&s_lists, lists_walked(m, x, y, t, px, py));
@@ -751,18 +790,22 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                     atomicAdd(&stats[1], (unsigned long long)last);
                     atomicAdd(&stats[2], (unsigned long long)s_lists);
                 }
+                if (s_hit)
+                {
+                    collided = true;
+                    break;
+                }
             }
-            if (s_hit)
-            {
-                collided = true;
-                break;
-            }
+        }
+        if (!STATS)
+        {
+            __syncthreads();
+            collided = s_hit != 0;
         }
         if (CLOCKS)
         {
             c1 = clock64();
-            if (tid == 0)
-                atomicAdd(&stats[10], (unsigned long long)(c1 - c2));
+            t_collide += c1 - c2;
         }
     }
     if (tid == 0)
@@ -777,6 +820,23 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             atomicAdd(&stats[0], tested);
         if (tid == 0)
             atomicAdd(&stats[7], 1ull);
+    }
+    if (CLOCKS)
+    {
+        if (lane == 0)
+            atomicAdd(&stats[11 + wave], (unsigned long long)t_wave);
+        if (lane == 0 && (wave == 0 || wave == 2)) // pose tests of wave 0, swept-segment tests of wave 2
+            atomicAdd(&stats[17 + wave / 2], (unsigned long long)t_test);
+        if (tid == 0)
+        {
+            atomicAdd(&stats[6], 1ull);
+            atomicAdd(&stats[8], (unsigned long long)t_solve);
+            atomicAdd(&stats[9], (unsigned long long)t_interp);
+            atomicAdd(&stats[10], (unsigned long long)t_collide);
+            atomicAdd(&stats[19], (unsigned long long)n_batches);
+            atomicAdd(&stats[15], (unsigned long long)t_load);
+            atomicAdd(&stats[16], (unsigned long long)(clock64() - c0)); // whole workgroup
+        }
     }
 }
 
