@@ -174,6 +174,18 @@ HY_HD_CALL double hy_cos(double x)
     }
 }
 
+/* sin and cos of one argument from one range reduction and both kernels:
+ * *s == hy_sin(x) and *c == hy_cos(x) bit for bit (the same operations on the
+ * same values; only the selection by quadrant is written without branches). */
+HY_HD void hy_sincos(double x, double *s, double *c)
+{
+    int q;
+    double r = hy_rem_pio2(x, &q);
+    double sk = hy_sin_kernel(r), ck = hy_cos_kernel(r);
+    *s = (q == 0) ? sk : (q == 1) ? ck : (q == 2) ? -sk : -ck;
+    *c = (q == 0) ? ck : (q == 1) ? -sk : (q == 2) ? -ck : sk;
+}
+
 /* ---- atan / atan2 / asin / acos ---------------------------------------- */
 
 /* atan on [0, 1]: nearest table point c = i/4, then the odd Taylor series in

@@ -8,7 +8,7 @@
 
 #include "hyas_kernels.h"
 
-#define HYAS_MAX_GROUPS 8
+#define HYAS_MAX_GROUPS 16
 
 struct hyas_ctx
 {

@@ -254,6 +254,13 @@ __device__ __forceinline__ double wave_min(double v)
     return v;
 }
 
+// v of lane `src` (wave-uniform), as a wave-uniform value
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // Lanes 0..43 of one wave evaluate one Reeds-Shepp candidate each; the five
 // families are then reduced in reference order.  Every lane returns the path.
 __device__ __forceinline__ rs::Path solve_wave(double x, double y, double phi, int lane)
@@ -380,12 +387,6 @@ struct StepQuads
 #define STEP_MIN_WAVES 4 // waves per SIMD the register allocation must allow: three workgroups per CU
 #endif
 
-struct CandOut
-{
-    rs::Path p;
-    double L;
-    int valid;
-};
 
 // rs::build_prefix with the sines and cosines of the six headings given (sn[i], cs[i] in front of segment i).
 __device__ __forceinline__ void prefix_from_sincos(const rs::Path &path, double phi0, const double *sn, const double *cs, rs::Prefix &P)
@@ -446,7 +447,9 @@ __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float
 // MODE 0: plain; 1: work counters (stats[3..6]).
 // 256 threads: with several nodes per query in a launch the chip is busy, and four-wave workgroups pack better than
 // eight-wave ones (512 threads measured 3 % slower on 1024 maze queries, 15 % slower on 8192 large-map queries)
+#ifndef ROUND_THREADS
 #define ROUND_THREADS 256
+#endif
 #define EXPAND_THREADS ROUND_THREADS
 #define SHOT_THREADS ROUND_THREADS
 
@@ -543,9 +546,8 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
 
 // Analytic Reeds-Shepp shot of one popped node (src/hybrid_a_star.cpp:429-468),
 // one workgroup of four waves per node.
-//  phase 1: the 44 closed-form candidates, grouped so that a wave runs two or
-//           three of the eight closed forms;
-//  phase 2: wave 0 reduces the candidates in reference order and builds the
+//  phase 1: the 44 closed-form candidates, one per lane of wave 0;
+//  phase 2: the same wave picks the winner in reference order and builds the
 //           per-segment prefix of the winning curve;
 //  phase 3: all lanes interpolate 256 samples of the curve at a time; the
 //           samples are then tested 128 at a time, pose tests on waves 0-1 and
@@ -553,20 +555,19 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
 // stats[] (MODE 1): 0 samples tested, 1 samples up to and including the first
 // colliding one (what a serial scan tests), 2 obstacle-list entries behind (1),
 // 7 shots; (MODE 2) shader-clock sums: 8 phases 1+2, 9 interpolation,
-// 10 collision tests, 11..14 phase 1 per wave, 6 workgroups, 19 sample batches.
+// 10 collision tests, 11 phase 1, 15 arrival of node and goal, 16 whole workgroup, 17 / 18 pose / swept-segment
+// tests of waves 0 / 2, 6 workgroups, 19 sample batches.
 template <int MODE, int CURVE>
 __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restrict__ in, const hyas_goal *__restrict__ goals,
                                           const double *__restrict__ seg_tab, uint32_t seg_cap, uint8_t *__restrict__ shot_ok,
                                           float *__restrict__ shot_len, unsigned long long *stats, Quad *s_quads, uint32_t slot)
 {
-    __shared__ CandOut s_cand[RS_NUM_CANDIDATES];
     __shared__ rs::Path s_path;
     __shared__ rs::Prefix s_prefix;
     __shared__ db::Path s_dubins;
     __shared__ float s_xyt[SHOT_THREADS + 1][3]; // [0] = the sample in front of this batch
     __shared__ volatile int s_hit;
     __shared__ unsigned int s_first, s_lists;
-    __shared__ double s_sn[6], s_cs[6]; // sin / cos of the heading in front of segment i (5: behind the last)
     constexpr bool RS = CURVE == HYAS_CURVE_RS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StepIn node = in[slot];
@@ -611,73 +612,72 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t;
         }
     }
-    else
+    else if (wave == (int)(slot % (SHOT_THREADS / 64)))
     {
-        // candidate groups per wave (group = closed form x backwards?, four symmetries each)
-        const int groups[4][3] = {{0, 1, 10}, {2, 3, 9}, {4, 5, -1}, {6, 8, 7}};
-        const int g = (lane < 12) ? groups[wave][lane >> 2] : -1;
-        if (g >= 0)
+        // (which wave: the waves of a workgroup sit on different SIMDs, and workgroups that start together on one
+        // compute unit should not all keep the same SIMD busy while the other three idle)
+        // Phases 1 and 2 on one wave, nothing leaves its registers in between: lane c evaluates candidate c in the
+        // side-by-side form (the time of the longest closed form, not the sum of all), the wave walks the 44 results
+        // in reference order on uniform values, six lanes take sine and cosine of the heading in front of each
+        // segment, and lane 0 stores the curve and its per-segment prefix states.
+        const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
+        double x, y, phi;
+        rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
+        rs::Path mine = rs::empty_path();
+        double my_L = __builtin_huge_val();
+        if (lane < RS_NUM_CANDIDATES)
         {
-            const int c = g * 4 + (lane & 3);
-            const double q1[3] = {(double)goal.x, (double)goal.y, (double)goal.t};
-            double x, y, phi;
-            rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
-            CandOut o;
-            o.L = 0;
-            o.valid = rs::candidate(c, x, y, phi, o.p, o.L) ? 1 : 0;
-            s_cand[c] = o;
+            double L = 0;
+            if (rs::candidate_staged(lane, x, y, phi, mine, L) && L == L)
+                my_L = L; // an invalid or NaN length never wins: lmin > L is false for +inf
         }
-        if (tid == 0)
-            s_hit = 0;
-    }
-    if (CLOCKS)
-        t_wave = clock64() - c0; // per-wave phase-1 time
-    __syncthreads();
-
-    // ---- phase 2 ------------------------------------------------------------
-    // Waves 0 and 1 both walk the 44 results in reference order (broadcast LDS reads: far shorter than reducing
-    // across lanes) and derive the heading in front of every segment; six lanes of wave 0 take the sines of the six
-    // headings, six lanes of wave 1 the cosines; thread 0 then accumulates the per-segment prefix states.
-    rs::Path best = rs::empty_path();
-    if (RS && wave < 2)
-    {
+        if (CLOCKS)
+            t_wave = clock64() - c0;
         int win = -1;
-        double best_total = best.total;
+        double best_total = rs::empty_path().total;
+        constexpr int first[RS_NUM_FAMILIES + 1] = {0, 8, 16, 24, 40, 44}; // rs::family_first
+#pragma unroll
         for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
         {
             double lmin = rs::family_bound(fam, best_total);
-            for (int c = rs::family_first(fam); c < rs::family_first(fam + 1); ++c)
+#pragma unroll
+            for (int c = first[fam]; c < first[fam + 1]; ++c)
             {
-                const CandOut &o = s_cand[c];
-                if (o.valid != 0 && lmin > o.L)
-                    win = c, lmin = o.L, best_total = o.p.total;
+                const double L = lane_value(my_L, c);
+                if (lmin > L)
+                    win = c, lmin = L, best_total = lane_value(mine.total, c);
             }
         }
-        if (win >= 0)
-            best = s_cand[win].p;
-        double my_phi = q0[2], phi = q0[2];
+        rs::Path best = rs::empty_path();
+        if (win >= 0) // uniform
+        {
+            best.type = __builtin_amdgcn_readlane(mine.type, win);
+            for (int i = 0; i < 5; ++i)
+                best.len[i] = lane_value(mine.len[i], win);
+            best.total = lane_value(mine.total, win);
+        }
+        double my_phi = q0[2], ph = q0[2];
         for (int i = 0; i < 5; ++i)
         {
             const int kind = rs::seg_kind(best.type, i);
-            phi = (kind == 1) ? phi + best.len[i] : (kind == 3) ? phi - best.len[i] : phi;
-            my_phi = (lane == i + 1) ? phi : my_phi;
+            ph = (kind == 1) ? ph + best.len[i] : (kind == 3) ? ph - best.len[i] : ph;
+            my_phi = (lane == i + 1) ? ph : my_phi;
         }
-        if (lane < 6)
+        double my_s, my_c;
+        hy_sincos(my_phi, &my_s, &my_c);
+        double sn[6], cs[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            sn[i] = lane_value(my_s, i), cs[i] = lane_value(my_c, i);
+        if (lane == 0)
         {
-            if (wave == 0)
-                s_sn[lane] = hy_sin(my_phi);
-            else
-                s_cs[lane] = hy_cos(my_phi);
+            rs::Prefix pf;
+            prefix_from_sincos(best, q0[2], sn, cs, pf);
+            s_path = best;
+            s_prefix = pf;
+            s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t; // predecessor of sample 0: the node
+            s_hit = 0;
         }
-    }
-    __syncthreads();
-    if (RS && tid == 0)
-    {
-        rs::Prefix pf;
-        prefix_from_sincos(best, q0[2], s_sn, s_cs, pf);
-        s_path = best;
-        s_prefix = pf;
-        s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t; // predecessor of sample 0: the node
     }
     __syncthreads();
     if (CLOCKS)

@@ -228,28 +228,10 @@ RS_HD int family_first(int fam)
     return first[fam];
 }
 
-// Evaluates candidate c for the normalised goal (x, y, phi).  On success fills
-// p (word, signed lengths, total) and L, the length the family compares
-// (|t|+|u|+|v|, with 2|u| in the CCCC family).
-RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
+// From (t, u, v) of the base formula to the path record: the length the family compares, the symmetry's signs,
+// the word and the segment layout (:110-158, :177-227, :262-310, :347-447, :469-492).
+RS_HD void candidate_tail(int family, int word, int layout, bool flip, bool reflect, double t, double u, double v, Path &p, double &L)
 {
-    int formula, backwards, family, word, layout;
-    group_info(c >> 2, formula, backwards, family, word, layout);
-    const int sym = c & 3;
-    double X = x, Y = y;
-    if (backwards) // :205, :400
-    {
-        double cp = hy_cos(phi), sp = hy_sin(phi);
-        X = x * cp + y * sp;
-        Y = x * sp - y * cp;
-    }
-    const bool flip = (sym & 1) != 0, reflect = (sym & 2) != 0;
-    const double ax = flip ? -X : X;
-    const double ay = reflect ? -Y : Y;
-    const double aphi = (flip != reflect) ? -phi : phi;
-    double t, u, v;
-    if (!base_formula(formula, ax, ay, aphi, t, u, v))
-        return false;
     L = (family == 2) ? hy_fabs(t) + 2. * hy_fabs(u) + hy_fabs(v) : hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
     const double hp = flip ? .5 * RS_PI : -.5 * RS_PI; // the fixed quarter turn of CCSC/CCSCC
     if (flip)
@@ -282,6 +264,220 @@ RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
     }
     p.len[0] = a, p.len[1] = b, p.len[2] = cc, p.len[3] = d, p.len[4] = e;
     p.total = hy_fabs(a) + hy_fabs(b) + hy_fabs(cc) + hy_fabs(d) + hy_fabs(e); // :527-537
+}
+
+
+// Evaluates candidate c for the normalised goal (x, y, phi).  On success fills
+// p (word, signed lengths, total) and L, the length the family compares
+// (|t|+|u|+|v|, with 2|u| in the CCCC family).
+RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
+{
+    int formula, backwards, family, word, layout;
+    group_info(c >> 2, formula, backwards, family, word, layout);
+    const int sym = c & 3;
+    double X = x, Y = y;
+    if (backwards) // :205, :400
+    {
+        double cp = hy_cos(phi), sp = hy_sin(phi);
+        X = x * cp + y * sp;
+        Y = x * sp - y * cp;
+    }
+    const bool flip = (sym & 1) != 0, reflect = (sym & 2) != 0;
+    const double ax = flip ? -X : X;
+    const double ay = reflect ? -Y : Y;
+    const double aphi = (flip != reflect) ? -phi : phi;
+    double t, u, v;
+    if (!base_formula(formula, ax, ay, aphi, t, u, v))
+        return false;
+    candidate_tail(family, word, layout, flip, reflect, t, u, v, p, L);
+    return true;
+}
+
+// candidate() arranged for lanes that evaluate different candidates side by side: what differs between the closed
+// forms is a few additions and comparisons, kept in small switches, while every costly function (sincos, sqrt,
+// atan2, the fmod inside mod2pi) sits in code all candidates pass through with their own arguments.  Forty-four
+// lanes of one wave then spend the time of the longest form instead of the sum of the forms they hold.  Every
+// candidate performs exactly the operations of base_formula_body() on exactly the same values, so the results are
+// equal bit for bit; arguments of a candidate already known to fail are replaced by harmless ones.
+RS_HD bool candidate_staged(int c, double x, double y, double phi, Path &p, double &L)
+{
+    int formula, backwards, family, word, layout;
+    group_info(c >> 2, formula, backwards, family, word, layout);
+    const int sym = c & 3;
+    double s0, c0;
+    hy_sincos(phi, &s0, &c0);
+    double X = x, Y = y;
+    if (backwards) // :205, :400
+    {
+        X = x * c0 + y * s0;
+        Y = x * s0 - y * c0;
+    }
+    const bool flip = (sym & 1) != 0, reflect = (sym & 2) != 0;
+    const double ax = flip ? -X : X;
+    const double ay = reflect ? -Y : Y;
+    const double aphi = (flip != reflect) ? -phi : phi;
+    double sp, cp;
+    hy_sincos(aphi, &sp, &cp);
+
+    // stage 1: the polar form every closed form starts from
+    const bool plus = formula == 1 || formula == 3 || formula == 4 || formula == 6 || formula == 7;
+    const double xi = plus ? ax + sp : ax - sp;
+    const double eta = plus ? ay - 1. - cp : ay - 1. + cp;
+    const double pa = (formula == 6) ? -eta : xi, pb = (formula == 6) ? xi : eta;
+    const double R = hy_sqrt(pa * pa + pb * pb);
+    const double TH = hy_atan2(pb, pa);
+
+    // stage 2: one square root and one arc tangent
+    bool ok = true;
+    double sq_arg = 0., rho = 0., w = 0.;
+    switch (formula)
+    {
+    case 0:
+        ok = TH >= -RS_ZERO;
+        break;
+    case 1:
+    {
+        const double u1 = R * R;
+        ok = u1 >= 4.;
+        sq_arg = u1 - 4.;
+        break;
+    }
+    case 2:
+        ok = R <= 4.;
+        w = .25 * R;
+        sq_arg = (1.0 - w) * (1.0 + w);
+        break;
+    case 3:
+        rho = .25 * (2. + R);
+        ok = rho <= 1.;
+        sq_arg = (1.0 - rho) * (1.0 + rho);
+        break;
+    case 4:
+        rho = (20. - xi * xi - eta * eta) / 16.;
+        ok = rho >= 0 && rho <= 1;
+        sq_arg = (1.0 - rho) * (1.0 + rho);
+        break;
+    case 5:
+    case 7:
+        ok = R >= 2.;
+        sq_arg = R * R - 4.;
+        break;
+    default: // 6
+        ok = R >= 2.;
+        break;
+    }
+    const double SQ = hy_sqrt(ok ? sq_arg : 0.);
+    double at_y = 0., at_x = 1., u = 0.;
+    switch (formula)
+    {
+    case 1:
+        at_y = 2., at_x = SQ;
+        break;
+    case 2:
+        at_y = w, at_x = SQ;
+        break;
+    case 3:
+    case 4:
+        at_y = SQ, at_x = rho;
+        break;
+    case 5:
+        at_y = SQ, at_x = -2.;
+        break;
+    case 7:
+        u = 4. - SQ;
+        ok = ok && u <= RS_ZERO;
+        at_y = (4 - u) * xi - 2 * eta, at_x = -2 * xi + (u - 4) * eta;
+        break;
+    default:
+        break;
+    }
+    if (!ok)
+        at_y = 0., at_x = 1.;
+    const double AT = hy_atan2(at_y, at_x);
+
+    // stage 3: the two four-arc forms
+    double t = 0., v = 0.;
+    if (formula == 3 || formula == 4)
+    {
+        u = (formula == 3) ? AT : -AT;
+        if (formula == 4)
+            ok = ok && u >= -.5 * RS_PI;
+        if (ok)
+        {
+            tau_omega(u, (formula == 3) ? -u : u, xi, eta, aphi, t, v);
+            ok = t >= -RS_ZERO && ((formula == 3) ? v <= RS_ZERO : v >= -RS_ZERO);
+        }
+    }
+    else
+    {
+        // stage 4: up to two reductions to (-pi, pi]
+        double m1 = 0.;
+        switch (formula)
+        {
+        case 1:
+            u = SQ;
+            m1 = TH + AT;
+            break;
+        case 2:
+            u = -2. * AT;
+            m1 = TH + .5 * u + RS_PI;
+            break;
+        case 5:
+            u = 2. - SQ;
+            m1 = TH + AT;
+            break;
+        case 7:
+            m1 = AT;
+            break;
+        case 0:
+            u = R;
+            break;
+        default: // 6
+            u = 2. - R;
+            break;
+        }
+        const double M1 = mod2pi(ok ? m1 : 0.);
+        t = (formula == 0 || formula == 6) ? TH : M1;
+        double m2;
+        switch (formula)
+        {
+        case 0:
+            m2 = aphi - t;
+            break;
+        case 2:
+            m2 = aphi - t + u;
+            break;
+        case 5:
+            m2 = aphi - .5 * RS_PI - t;
+            break;
+        case 6:
+            m2 = t + .5 * RS_PI - aphi;
+            break;
+        default: // 1, 7
+            m2 = t - aphi;
+            break;
+        }
+        v = mod2pi(ok ? m2 : 0.);
+        switch (formula)
+        {
+        case 0:
+            ok = ok && v >= -RS_ZERO;
+            break;
+        case 1:
+        case 7:
+            ok = ok && t >= -RS_ZERO && v >= -RS_ZERO;
+            break;
+        case 2:
+            ok = ok && t >= -RS_ZERO && u <= RS_ZERO;
+            break;
+        default: // 5, 6
+            ok = ok && t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO;
+            break;
+        }
+    }
+    if (!ok)
+        return false;
+    candidate_tail(family, word, layout, flip, reflect, t, u, v, p, L);
     return true;
 }
 

@@ -3,10 +3,12 @@
 // can compare the exact code the kernels run against the oracle on adversarial
 // poses without a GPU.  The product library has no such path.
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "../../path_planner_amd/csrc/hyas_dev.h"
 #include "../../path_planner_amd/csrc/hyas_prune.h"
+#include "../../path_planner_amd/csrc/hyas_rs.h"
 
 using namespace hyas;
 
@@ -69,4 +71,49 @@ extern "C" int hg_collision(const float *quads8, int nq, const uint8_t *charmap,
         out[i] = ok ? 1 : 0;
     }
     return 0;
+}
+
+// The side-by-side form of the Reeds-Shepp candidates (rs::candidate_staged, what the shot kernel runs) against the
+// plain form (rs::candidate, what the table kernel and the oracle's restatement follow): number of (goal, candidate)
+// pairs whose validity, compared length or path record differ in any bit.  xyphi: n normalised goals (x, y, phi).
+extern "C" long hg_rs_staged_mismatches(const double *xyphi, int n, long *valid_out)
+{
+    long bad = 0, valid = 0;
+    for (int i = 0; i < n; i++)
+        for (int c = 0; c < RS_NUM_CANDIDATES; c++)
+        {
+            rs::Path a = rs::empty_path(), b = rs::empty_path();
+            double la = 0, lb = 0;
+            const bool oa = rs::candidate(c, xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2], a, la);
+            const bool ob = rs::candidate_staged(c, xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2], b, lb);
+            valid += oa;
+            if (oa != ob)
+            {
+                ++bad;
+                continue;
+            }
+            if (!oa)
+                continue;
+            bool same = a.type == b.type && std::memcmp(&la, &lb, 8) == 0 && std::memcmp(&a.total, &b.total, 8) == 0;
+            for (int k = 0; k < 5; k++)
+                same = same && std::memcmp(&a.len[k], &b.len[k], 8) == 0;
+            bad += !same;
+        }
+    if (valid_out)
+        *valid_out = valid;
+    return bad;
+}
+
+// hy_sincos against hy_sin and hy_cos: number of arguments where a bit differs.
+extern "C" long hg_sincos_mismatches(const double *x, int n)
+{
+    long bad = 0;
+    for (int i = 0; i < n; i++)
+    {
+        double s, c;
+        hy_sincos(x[i], &s, &c);
+        const double s1 = hy_sin(x[i]), c1 = hy_cos(x[i]);
+        bad += std::memcmp(&s, &s1, 8) != 0 || std::memcmp(&c, &c1, 8) != 0;
+    }
+    return bad;
 }

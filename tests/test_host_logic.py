@@ -22,7 +22,8 @@ HG = ROOT / "tests" / "host_geom"
 @pytest.fixture(scope="module")
 def host_geom():
     so, src = HG / "libhost_geom.so", HG / "host_geom.cpp"
-    deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h"]
+    deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h",
+            ROOT / "path_planner_amd/csrc/hyas_rs.h"]
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
                         "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
@@ -71,6 +72,28 @@ def test_device_geometry_and_pruning_match_oracle(map_name, host_geom, oracle_bu
         assert int((got2 != want_pose).sum()) == 0, (map_name, prune)
     assert 0.02 < want.mean() < 0.98
     assert ent[1] <= ent[0] and ent[2] <= 2 * ent[0]  # pruning never adds pose entries
+
+
+def test_side_by_side_reeds_shepp_candidates_equal_the_plain_form(host_geom):
+    """The shot kernel evaluates the 44 Reeds-Shepp candidates in a form laid out for lanes running side by side; it
+    must give the bits of the plain form (src/ReedsShepp.cpp:73-503 restated) for every candidate, valid or not."""
+    rng = np.random.default_rng(77)
+    n = 60000
+    g = np.stack([rng.uniform(-60, 60, n), rng.uniform(-60, 60, n), rng.uniform(-2 * math.pi, 2 * math.pi, n)], 1)
+    k = n // 6
+    g[:k, :2] = rng.uniform(-4.5, 4.5, (k, 2))  # inside the circles where the CCC / CCCC forms exist
+    g[k:2 * k, 2] = rng.choice([0.0, -0.0, math.pi, -math.pi, math.pi / 2, -math.pi / 2, 2 * math.pi], k)
+    g[2 * k:3 * k, 1] = rng.choice([0.0, -0.0, 1.0, -1.0, 2.0], k)
+    g[3 * k:3 * k + 8] = [[0, 0, 0], [-0.0, 0, 0], [0, -0.0, -0.0], [1e-12, 0, 0], [0, 2, math.pi], [4, 0, 0], [1e6, -1e6, 1], [2, 0, 0]]
+    g = np.ascontiguousarray(g, np.float64)
+    valid = C.c_long(0)
+    host_geom.hg_rs_staged_mismatches.restype = C.c_long
+    bad = host_geom.hg_rs_staged_mismatches(g.ctypes.data_as(C.c_void_p), n, C.byref(valid))
+    assert valid.value > 4 * n  # several candidates exist for a typical goal
+    assert bad == 0
+    x = np.concatenate([rng.uniform(-100, 100, 200000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, math.pi / 4, -math.pi / 4, 1e5, -1e5]])
+    host_geom.hg_sincos_mismatches.restype = C.c_long
+    assert host_geom.hg_sincos_mismatches(np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), len(x)) == 0
 
 
 def test_posestamped_yaw_round_trip():
