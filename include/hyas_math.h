@@ -275,6 +275,12 @@ HY_HD double hy_acos(double x)
 /* ---- float forms: evaluate in double, round once ------------------------ */
 HY_HD float hy_sinf(float x) { return (float)hy_sin((double)x); }
 HY_HD float hy_cosf(float x) { return (float)hy_cos((double)x); }
+HY_HD void hy_sincosf(float x, float *s, float *c) /* == (hy_sinf(x), hy_cosf(x)) */
+{
+    double sd, cd;
+    hy_sincos((double)x, &sd, &cd);
+    *s = (float)sd, *c = (float)cd;
+}
 HY_HD float hy_acosf(float x) { return (float)hy_acos((double)x); }
 HY_HD float hy_atan2f(float y, float x) { return (float)hy_atan2((double)y, (double)x); }
 

@@ -384,7 +384,8 @@ HD int idx_3d(const DevMap &m, float x, float y, float t)
 HD void vehicle_corners(const DevMap &m, float x, float y, float t, F2 c[4])
 {
     const float w = m.veh_len, h = m.veh_wid; // CreatePolygon(center, vehicle_length, vehicle_width, t)
-    const float ct = hy_cosf(t), st = hy_sinf(t);
+    float ct, st;
+    hy_sincosf(t, &st, &ct);
     const float m01 = -st;
     const float px[4] = {-w / 2, +w / 2, +w / 2, -w / 2};
     const float py[4] = {-h / 2, -h / 2, +h / 2, +h / 2};
@@ -734,7 +735,8 @@ HD bool successor_pose(const DevMap &m, float x, float y, float t, float dist_to
         dy = 0;
         prim = reverse_flag ? 3 : 0;
     }
-    const float ct = hy_cosf(t), sn = hy_sinf(t);
+    float ct, sn;
+    hy_sincosf(t, &sn, &ct);
     sx = x + dx * ct - dy * sn;
     sy = y + dx * sn + dy * ct;
     st = rad_0_2pi(t + steer);

@@ -452,6 +452,13 @@ __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float
 #endif
 #define EXPAND_THREADS ROUND_THREADS
 #define SHOT_THREADS ROUND_THREADS
+// samples of a curve interpolated per pass and then tested in rounds of SHOT_THREADS / 2 (half of the workgroup runs
+// the pose tests, half the swept-segment tests).  Passes of SHOT_THREADS / 2 samples would waste less work behind the
+// first colliding sample but measured slower (61 vs 54 us per launch on the 1024-query maze batch): the launch waits
+// for its longest curve, and that one pays a barrier pair per pass.
+#ifndef SHOT_BATCH
+#define SHOT_BATCH SHOT_THREADS
+#endif
 
 // workgroup-local copy of the obstacle quads when they fit (16 dwords each); the caller synchronises
 __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads, int tid)
@@ -565,7 +572,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     __shared__ rs::Path s_path;
     __shared__ rs::Prefix s_prefix;
     __shared__ db::Path s_dubins;
-    __shared__ float s_xyt[SHOT_THREADS + 1][3]; // [0] = the sample in front of this batch
+    __shared__ float s_xyt[SHOT_BATCH + 1][3]; // [0] = the sample in front of this batch
     __shared__ volatile int s_hit;
     __shared__ unsigned int s_first, s_lists;
     constexpr bool RS = CURVE == HYAS_CURVE_RS;
@@ -706,18 +713,18 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     }
     bool collided = false;
     unsigned long long tested = 0;
-    for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_THREADS)
+    for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_BATCH)
     {
         if (base)
         {
             __syncthreads(); // everyone is done with the previous batch
             if (tid == 0)
-                s_xyt[0][0] = s_xyt[SHOT_THREADS][0], s_xyt[0][1] = s_xyt[SHOT_THREADS][1];
+                s_xyt[0][0] = s_xyt[SHOT_BATCH][0], s_xyt[0][1] = s_xyt[SHOT_BATCH][1];
         }
         {
             const uint32_t k = base + tid;
             float x = 0, y = 0, t = 0;
-            if (k < nsamp)
+            if (tid < SHOT_BATCH && k < nsamp)
             {
                 if (RS)
                 {
@@ -733,8 +740,9 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                 }
             }
             if (base)
-                __syncthreads(); // slot 0 has been refreshed before slot SHOT_THREADS is overwritten
-            s_xyt[tid + 1][0] = x, s_xyt[tid + 1][1] = y, s_xyt[tid + 1][2] = t;
+                __syncthreads(); // slot 0 has been refreshed before slot SHOT_BATCH is overwritten
+            if (tid < SHOT_BATCH)
+                s_xyt[tid + 1][0] = x, s_xyt[tid + 1][1] = y, s_xyt[tid + 1][2] = t;
         }
         __syncthreads();
         if (CLOCKS)
@@ -744,7 +752,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         }
         // two test rounds: the first half of the workgroup runs the pose tests, the second half the swept-segment tests;
         // the workgroup meets once, after both (in between, the flag alone tells a lane that the shot is decided)
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < SHOT_BATCH / (SHOT_THREADS / 2); ++half)
         {
             const uint32_t j = half * (SHOT_THREADS / 2) + (tid & (SHOT_THREADS / 2 - 1)); // sample inside the batch
             const uint32_t k = base + j;

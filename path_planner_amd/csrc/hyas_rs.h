@@ -528,7 +528,8 @@ RS_HD void normalise(const double q0[3], const double q1[3], double rho, double 
 {
     double dx = q1[0] - q0[0], dy = q1[1] - q0[1];
     phi = q1[2] - q0[2];
-    double c = hy_cos(q0[2]), s = hy_sin(q0[2]);
+    double c, s;
+    hy_sincos(q0[2], &s, &c);
     x = (c * dx + s * dy) / rho;
     y = (-s * dx + c * dy) / rho;
 }
@@ -631,6 +632,8 @@ RS_HD void interpolate_prefix(const double q0[3], const Path &path, const Prefix
     if (seg > path.total)
         seg = path.total;
     double x = 0.0, y = 0.0, phi = q0[2];
+    int part = -1; // the segment the point lies inside, if any (always the last one the walk reaches)
+    double v_part = 0.0;
     for (int i = 0; i < 5 && seg > 0; ++i)
     {
         const double li = path.len[i];
@@ -650,19 +653,30 @@ RS_HD void interpolate_prefix(const double q0[3], const Path &path, const Prefix
             x = P.x[i + 1], y = P.y[i + 1], phi = P.phi[i + 1];
             continue;
         }
-        const double p0 = P.phi[i];
+        part = i, v_part = v;
+    }
+    if (part >= 0)
+    {
+        // one sine/cosine pair per point, outside the walk: lanes that stop in different segments share this code
+        const int i = part;
+        const double v = v_part, p0 = P.phi[i];
         const int kind = seg_kind(path.type, i);
-        if (kind == 1)
+        if (kind == 1 || kind == 3)
         {
-            x = P.x[i] + (hy_sin(p0 + v) - P.s[i]);
-            y = P.y[i] + (-hy_cos(p0 + v) + P.c[i]);
-            phi = p0 + v;
-        }
-        else if (kind == 3)
-        {
-            x = P.x[i] + (-hy_sin(p0 - v) + P.s[i]);
-            y = P.y[i] + (hy_cos(p0 - v) - P.c[i]);
-            phi = p0 - v;
+            const double a = (kind == 1) ? p0 + v : p0 - v;
+            double sa, ca;
+            hy_sincos(a, &sa, &ca);
+            if (kind == 1)
+            {
+                x = P.x[i] + (sa - P.s[i]);
+                y = P.y[i] + (-ca + P.c[i]);
+            }
+            else
+            {
+                x = P.x[i] + (-sa + P.s[i]);
+                y = P.y[i] + (ca - P.c[i]);
+            }
+            phi = a;
         }
         else if (kind == 2)
         {

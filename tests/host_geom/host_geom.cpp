@@ -117,3 +117,36 @@ extern "C" long hg_sincos_mismatches(const double *x, int n)
     }
     return bad;
 }
+
+// rs::interpolate_prefix (per-segment prefix states + one sine/cosine pair per point, what the shot kernel runs)
+// against rs::interpolate (the reference's walk, src/ReedsShepp.cpp:576-625): points whose state differs in any bit.
+// For each of the n goals the shortest curve from the origin pose (0, 0, phi0) is sampled at `per` arc lengths.
+extern "C" long hg_rs_interp_mismatches(const double *xyphi, int n, int per, double rho)
+{
+    long bad = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const double q0[3] = {0.25 * i, -0.5 * i, xyphi[3 * i + 2] * 0.7};
+        const rs::Path path = rs::solve_serial(xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2]);
+        if (!(path.total < 1e300))
+            continue;
+        rs::Prefix P;
+        rs::build_prefix(path, q0[2], P);
+        for (int k = 0; k <= per; k++)
+        {
+            // arc lengths across the whole curve, the exact segment ends among them
+            double seg = path.total * k / per;
+            if (k % 7 == 3)
+            {
+                seg = 0;
+                for (int j = 0; j <= (k / 7) % 5; j++)
+                    seg += std::fabs(path.len[j]);
+            }
+            double a[3], b[3];
+            rs::interpolate(q0, path, seg, rho, a);
+            rs::interpolate_prefix(q0, path, P, seg, rho, b);
+            bad += std::memcmp(a, b, 24) != 0;
+        }
+    }
+    return bad;
+}
