@@ -230,9 +230,13 @@ void hyas_reset_kernel_timers(hyas_ctx *ctx);
  * 0 curve samples tested, 1 samples a serial scan would test (up to and
  * including the first colliding one), 2 obstacle-list entries behind (1),
  * 3 successors that received a verdict, 4 obstacle-list entries behind (3),
- * 5 successors emitted, 6 nodes expanded, 7 shots evaluated; 8..10 shader
- * clock sums (curve solve + successors, sample interpolation, sample collision
- * tests), 11..15 the five waves' share of the first, 16 sample rounds. */
+ * 5 successors emitted, 6 nodes expanded (mode 2: shot workgroups), 7 shots
+ * evaluated; mode 2, shader clock sums over the shot workgroups: 8 curve
+ * solve, 9 sample interpolation, 10 sample collision tests, 11..14 time from
+ * the start of a workgroup to: goal frame normalised, candidates evaluated,
+ * winner known, prefix states stored; 15 arrival of node and goal, 16 whole
+ * workgroup, 17 / 18 pose / swept-segment tests of one wave each, 19 sample
+ * passes.  The same modes apply to hyas_shot_batch and hyas_expand_batch. */
 int hyas_set_stats(hyas_ctx *ctx, int enable);
 int hyas_get_stats(hyas_ctx *ctx, uint64_t out[24]);
 

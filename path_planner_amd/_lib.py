@@ -331,6 +331,6 @@ class Hyas:
         out = np.zeros(24, np.uint64)
         self._check(self.L.hyas_get_stats(self.h, _vp(out)), "hyas_get_stats")
         names = ["samples_tested", "samples_serial", "sample_list_entries", "succ_evaluated", "succ_list_entries",
-                 "succ_emitted", "nodes", "shots", "clk_solve", "clk_interp", "clk_collide", "clk_w0", "clk_w1",
-                 "clk_w2", "clk_w3", "clk_w4", "clk_w5", "clk_w6", "clk_w7", "rounds"]
+                 "succ_emitted", "nodes", "shots", "clk_solve", "clk_interp", "clk_collide", "clk_to_frame", "clk_to_candidates",
+                 "clk_to_winner", "clk_to_prefix", "clk_to_inputs", "clk_workgroup", "clk_pose_wave", "clk_segment_wave", "rounds"]
         return dict(zip(names, (int(v) for v in out)))

@@ -975,10 +975,10 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
     timer_begin(c);
     if (shoot)
         launch_shot(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), c->d_seg, c->seg_cap,
-                       (uint8_t *)(ds + o_ok), (float *)(ds + o_len), nullptr, 0, c->stream);
+                       (uint8_t *)(ds + o_ok), (float *)(ds + o_len), c->stats_on ? c->d_stats : nullptr, c->stats_mode, c->stream);
     else
         launch_expand(c->dm, (const StepIn *)(ds + o_in), (uint32_t)n, (const hyas_goal *)(ds + o_goal), twod ? c->d_twod : nullptr,
-                      (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), nullptr, 0, c->stream);
+                      (uint8_t *)(ds + o_cnt), (hyas_succ *)(ds + o_succ), c->stats_on ? c->d_stats : nullptr, c->stats_mode, c->stream);
     HYAS_HIP(c, hipGetLastError());
     HYAS_HIP(c, hipStreamSynchronize(c->stream));
     timer_end(c, shoot ? 0 : 1);

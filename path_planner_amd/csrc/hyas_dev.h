@@ -44,7 +44,7 @@ HD float fminf_(float a, float b) { return b < a ? b : a; }          // std::min
 
 // One obstacle quadrilateral: vertices 0..3 (vertex 4 == vertex 0 in the
 // reference's closed polygon) and its axis-aligned bounds.
-struct Quad
+struct alignas(16) Quad
 {
     float vx[4], vy[4];
     float xmin, ymin, xmax, ymax;

@@ -460,16 +460,35 @@ __device__ __forceinline__ uint32_t lists_walked(const DevMap &m, float x, float
 #define SHOT_BATCH SHOT_THREADS
 #endif
 
-// workgroup-local copy of the obstacle quads when they fit (16 dwords each); the caller synchronises
-__device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads, int tid)
+// workgroup-local copy of the obstacle quads when they fit (four 16-byte words each); the caller synchronises.
+// Threads [first, ROUND_THREADS) copy: the shot role keeps the wave that solves the curve out of it.  All loads of a
+// thread are requested before the first store, so the copy costs one trip to memory, not one per word.
+__device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads, int tid, int first = 0, int count = ROUND_THREADS)
 {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const bool quads_local = m.n_quads <= STEP_LDS_QUADS;
-    if (quads_local)
+    const int t = tid - first;
+    if (quads_local && t >= 0 && t < count)
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(m.quads);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(s_quads);
-        for (uint32_t i = tid; i < m.n_quads * 16u; i += ROUND_THREADS)
-            dst[i] = src[i];
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(m.quads);
+        HYAS_LDS u32x4 *dst = (HYAS_LDS u32x4 *)s_quads;
+        const uint32_t words = m.n_quads * 4u;
+        constexpr int PER = (STEP_LDS_QUADS * 4 + ROUND_THREADS - 64 - 1) / (ROUND_THREADS - 64); // enough for three waves
+        u32x4 w[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+        {
+            const uint32_t i = (uint32_t)t + (uint32_t)j * (uint32_t)count;
+            if (i < words)
+                w[j] = src[i];
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+        {
+            const uint32_t i = (uint32_t)t + (uint32_t)j * (uint32_t)count;
+            if (i < words)
+                dst[i] = w[j];
+        }
     }
     return StepQuads{(const HYAS_LDS Quad *)s_quads, m.quads, nullptr, quads_local, false};
 }
@@ -562,8 +581,9 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
 // stats[] (MODE 1): 0 samples tested, 1 samples up to and including the first
 // colliding one (what a serial scan tests), 2 obstacle-list entries behind (1),
 // 7 shots; (MODE 2) shader-clock sums: 8 phases 1+2, 9 interpolation,
-// 10 collision tests, 11 phase 1, 15 arrival of node and goal, 16 whole workgroup, 17 / 18 pose / swept-segment
-// tests of waves 0 / 2, 6 workgroups, 19 sample batches.
+// 10 collision tests, 11..14 time from the start to: frame normalised, candidates evaluated, winner known, prefix
+// stored; 15 arrival of node and goal, 16 whole workgroup, 17 / 18 pose / swept-segment tests of waves 0 / 2,
+// 6 workgroups, 19 sample passes.
 template <int MODE, int CURVE>
 __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restrict__ in, const hyas_goal *__restrict__ goals,
                                           const double *__restrict__ seg_tab, uint32_t seg_cap, uint8_t *__restrict__ shot_ok,
@@ -587,7 +607,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     constexpr bool STATS = MODE == 1, CLOCKS = MODE == 2;
     // clock sums are kept in registers and added to stats[] once, at the end: atomics inside the phases would be
     // waited for at the next barrier and lengthen what they measure
-    long long c0 = 0, c1 = 0, c2 = 0, t_wave = 0, t_solve = 0, t_interp = 0, t_collide = 0, t_load = 0, t_test = 0;
+    long long c0 = 0, c1 = 0, c2 = 0, t_wave = 0, t_solve = 0, t_interp = 0, t_collide = 0, t_load = 0, t_test = 0, mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0;
     unsigned n_batches = 0;
     if (CLOCKS)
         c0 = clock64();
@@ -599,7 +619,10 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         if (__float_as_uint(goal.x) + __float_as_uint(node.x) != 0x12345u)
             t_load = clock64() - c0;
     }
-    StepQuads sq = stage_quads(m, s_quads, tid); // visible after the barrier that ends phase 1
+    // the quads are copied by the waves that do not solve the curve; visible after the barrier that ends phase 2
+    constexpr int N_WAVES = SHOT_THREADS / 64;
+    const int solver = RS ? (int)(slot % N_WAVES) : 0;
+    StepQuads sq = stage_quads(m, s_quads, (tid + (N_WAVES - 1 - solver) * 64) % SHOT_THREADS, 0, SHOT_THREADS - 64);
     if (!STATS) // one colliding sample decides the shot: the other lanes stop walking their lists
         sq.flag = (volatile HYAS_LDS int *)&s_hit, sq.flagged = true;
 
@@ -619,7 +642,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t;
         }
     }
-    else if (wave == (int)(slot % (SHOT_THREADS / 64)))
+    else if (wave == solver)
     {
         // (which wave: the waves of a workgroup sit on different SIMDs, and workgroups that start together on one
         // compute unit should not all keep the same SIMD busy while the other three idle)
@@ -632,6 +655,8 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         rs::normalise(q0, q1, (double)m.shot_rho, x, y, phi);
         rs::Path mine = rs::empty_path();
         double my_L = __builtin_huge_val();
+        if (CLOCKS)
+            mk0 = clock64() - c0; // goal loaded, frame normalised
         if (lane < RS_NUM_CANDIDATES)
         {
             double L = 0;
@@ -639,7 +664,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                 my_L = L; // an invalid or NaN length never wins: lmin > L is false for +inf
         }
         if (CLOCKS)
-            t_wave = clock64() - c0;
+            t_wave = mk1 = clock64() - c0; // candidates evaluated
         int win = -1;
         double best_total = rs::empty_path().total;
         constexpr int first[RS_NUM_FAMILIES + 1] = {0, 8, 16, 24, 40, 44}; // rs::family_first
@@ -663,6 +688,8 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                 best.len[i] = lane_value(mine.len[i], win);
             best.total = lane_value(mine.total, win);
         }
+        if (CLOCKS)
+            mk2 = clock64() - c0; // winner known
         double my_phi = q0[2], ph = q0[2];
         for (int i = 0; i < 5; ++i)
         {
@@ -685,6 +712,8 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t; // predecessor of sample 0: the node
             s_hit = 0;
         }
+        if (CLOCKS)
+            mk3 = clock64() - c0; // prefix stored
     }
     __syncthreads();
     if (CLOCKS)
@@ -831,8 +860,11 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     }
     if (CLOCKS)
     {
-        if (lane == 0)
-            atomicAdd(&stats[11 + wave], (unsigned long long)t_wave);
+        if (lane == 0 && wave == solver)
+        {
+            atomicAdd(&stats[11], (unsigned long long)mk0), atomicAdd(&stats[12], (unsigned long long)mk1);
+            atomicAdd(&stats[13], (unsigned long long)mk2), atomicAdd(&stats[14], (unsigned long long)mk3);
+        }
         if (lane == 0 && (wave == 0 || wave == 2)) // pose tests of wave 0, swept-segment tests of wave 2
             atomicAdd(&stats[17 + wave / 2], (unsigned long long)t_test);
         if (tid == 0)

@@ -116,6 +116,7 @@ struct Query
     // expanded ahead of time in case one of them is popped right after cur
     int32_t spec[HYAS_MAX_SPEC];
     int nspec = 0;
+    int spec_w = 2; // how many of them to send next round: follows how far down the list the search has been landing
     bool shoot = false;
     bool done = false;
     int shot_from = -1; // >= 0: finished through an analytic shot from this node
@@ -589,8 +590,12 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // Nodes of one query expanded per round: its popped node plus the next best open-list entries, whose
     // results are used only if the search pops exactly that node next (it often does on plateaus of equal cost),
     // which saves the round trip.  The answers are those of one node per round.
-    // Wider pays while a group's launch is short: 6 for groups of up to 256 queries, else 4.
-    int spec_cfg = 0; // 0 = choose per chunk
+    // A query sends fewer extra nodes while its speculation is not paying off: two beyond the deepest entry the
+    // search used last round, one less (down to HYAS_SPEC_FLOOR) after a round that used none.  HYAS_SPEC_ADAPT=0
+    // sends the full width every round.
+    const bool spec_adapt = !(std::getenv("HYAS_SPEC_ADAPT") && std::atoi(std::getenv("HYAS_SPEC_ADAPT")) == 0);
+    const int spec_floor = std::getenv("HYAS_SPEC_FLOOR") ? std::max(0, std::atoi(std::getenv("HYAS_SPEC_FLOOR"))) : 2;
+    int spec_cfg = 6;
     if (const char *e = std::getenv("HYAS_SPEC"))
         spec_cfg = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
     const size_t twod = c->twod_size;
@@ -608,7 +613,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
         const int ng = (int)std::max<size_t>(1, std::min<size_t>(n_groups, cn / 32 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
-        const int spec_k = spec_cfg ? spec_cfg : (gcap <= 256 ? 6 : 4);
+        const int spec_k = spec_cfg;
         const size_t KS = (size_t)spec_k;
         const size_t o_in = take(cn * KS * sizeof(StepIn));
         int max_drivers = 4; // 4 = hardware queues of a process
@@ -773,6 +778,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     if (have_results)
                     {
                         int at = 0; // which of the query's nodes of the last launch is being consumed
+                        int deepest = 0;
                         for (;;)
                         {
                             const size_t sl = slot0[qi] + at;
@@ -788,8 +794,12 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             if (j < 0)
                                 break; // no: it goes to the GPU
                             at = j;
+                            deepest = std::max(deepest, j);
                             ++hits;
                         }
+                        // width of the next round: two beyond the deepest entry that was used, one less when none was
+                        if (spec_adapt)
+                            q.spec_w = deepest ? std::min(spec_k - 1, deepest + 2) : std::max(spec_floor, q.spec_w - 1);
                     }
                     else
                         want = !q.done && D.advance(q);
@@ -797,7 +807,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     if (want)
                     {
                         q.spec[0] = q.cur;
-                        q.nspec = 1 + (spec_k > 1 ? D.next_best(q, q.spec + 1, spec_k - 1) : 0);
+                        const int extra = spec_adapt ? std::min(q.spec_w, spec_k - 1) : spec_k - 1;
+                        q.nspec = 1 + (extra > 0 ? D.next_best(q, q.spec + 1, extra) : 0);
                         for (int i = 0; i < q.nspec; ++i)
                         {
                             const SNode &nd = q.arena[q.spec[i]];
