@@ -15,3 +15,10 @@ cp gpurun_out/meas/prof/bench_kernel_stats.csv gpurun_out/meas/kernel_stats.csv
 rm -rf gpurun_out/meas/prof
 echo "kernel stats done"
 bash profiles/collect_traffic.sh
+# 4. the other configurations (bench.py --workload ...)
+timeout -k 10 300 python3 -u bench.py --workload footprint_checks > gpurun_out/meas/extra_footprint.json
+timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 1 > gpurun_out/meas/extra_table_pr1.json
+timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 10 > gpurun_out/meas/extra_table_pr10.json
+echo "extras done"
+HYAS_TRACE=1 timeout -k 10 600 python3 -u bench.py --workload queries_large --steps 1 --warmup 0 > gpurun_out/meas/extra_queries_large.json 2> gpurun_out/meas/extra_queries_large.log
+echo "large done"

@@ -16,3 +16,6 @@ if line.get("roofline"):
 open(f"profiles/{r}_bench_line.json", "w").write(json.dumps(line) + "\n")
 print(json.dumps(line)[:600])
 PY
+for x in footprint table_pr1 table_pr10 queries_large; do
+    [ -s gpurun_out/meas/extra_$x.json ] && tail -n 1 gpurun_out/meas/extra_$x.json > profiles/${r}_extra_$x.json
+done
