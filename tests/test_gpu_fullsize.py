@@ -155,8 +155,10 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
     keep = [(h.path(i), h.expanded(i)) for i in range(300)]
     assert base["nodes_expanded"].sum() > 100000
     for env in (dict(HYAS_SPEC="1", HYAS_GROUPS="1", HYAS_THREADS="1"), dict(HYAS_SPEC="2", HYAS_GROUPS="3", HYAS_THREADS="5"),
-                dict(HYAS_SPEC="8", HYAS_GROUPS="8", HYAS_THREADS="16"), dict(HYAS_SPEC="4", HYAS_CHUNK="97")):
-        for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK"):
+                dict(HYAS_SPEC="8", HYAS_GROUPS="8", HYAS_THREADS="16"), dict(HYAS_SPEC="4", HYAS_CHUNK="97"),
+                dict(HYAS_SPEC="8", HYAS_SPEC_ADAPT="0", HYAS_GROUPS="16", HYAS_DRIVERS="2"),
+                dict(HYAS_SPEC="5", HYAS_SPEC_FLOOR="0", HYAS_DRIVERS="8")):
+        for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
