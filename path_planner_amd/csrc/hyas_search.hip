@@ -40,6 +40,7 @@ struct HeapItem
     float f;
     uint32_t seq;
     int32_t node;
+    int32_t idx; // the node's cell (Node3D::setIdx), as the kernel computed it: not recomputed at every look
 };
 // Open list order: lowest f = g + h first (CompareNodes, include/hybrid_a_star.h:31-43); equal f: earliest
 // push first.  (Boost's binomial heap leaves the order of equal keys unspecified.)  See Driver::before().
@@ -203,11 +204,11 @@ struct Driver
     {
         bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f > b.f || (a.f == b.f && a.seq > b.seq); }
     };
-    void push(Query &q, const SNode &n)
+    void push(Query &q, const SNode &n, int32_t idx)
     {
         q.arena.push_back(n);
         int32_t id = (int32_t)q.arena.size() - 1;
-        q.heap.push_back(HeapItem{n.g + n.h, q.seq++, id}); // getTotalCost(), include/node3d.h:36
+        q.heap.push_back(HeapItem{n.g + n.h, q.seq++, id, idx}); // getTotalCost(), include/node3d.h:36
         std::push_heap(q.heap.begin(), q.heap.end(), After());
         dup_insert(q, id);
     }
@@ -238,8 +239,7 @@ struct Driver
                     b = i;
             const size_t at = cand[b];
             cand[b] = cand[--nc];
-            const SNode &n = q.arena[h[at].node];
-            CellMap::Slot *cell = q.cells.find(idx_3d(m, n.x, n.y, n.t));
+            CellMap::Slot *cell = q.cells.find(h[at].idx);
             if (!(cell && cell->closed))
                 out[got++] = h[at].node;
             if (2 * at + 1 < h.size() && nc < (int)(sizeof cand / sizeof cand[0]))
@@ -311,7 +311,7 @@ struct Driver
             const int32_t pid = q.heap.front().node;
             q.res.nodes_explored++;
             const SNode &n = q.arena[pid];
-            const int32_t iPred = idx_3d(m, n.x, n.y, n.t);
+            const int32_t iPred = q.heap.front().idx;
             q.iterations++;
             CellMap::Slot &cell = q.cells.get(iPred);
             if (cell.closed)
@@ -409,7 +409,7 @@ struct Driver
                     n.pred = pred.pred;
                 }
                 cell.g = n.g, cell.open = 1, cell.closed = 0;
-                push(q, n);
+                push(q, n, iSucc);
             }
         }
     }
@@ -702,7 +702,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     two_d = h_twod[i * twod + id];
                 q.start.h = fmaxf_(cost[i], two_d);
                 q.N = (int)q.start.h;
-                D.push(q, q.start);
+                D.push(q, q.start, idx_3d(c->dm, q.start.x, q.start.y, q.start.t));
                 CellMap::Slot &cell = q.cells.get(idx_3d(m, q.start.x, q.start.y, q.start.t));
                 cell.g = q.start.g, cell.open = 1, cell.closed = 0;
             }
