@@ -440,28 +440,32 @@ HD bool vehicle_hits_quad(F2 c0, F2 c1, F2 c2, F2 c3, const Quad &q)
 template <class QuadSrc>
 HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float t)
 {
-    uint32_t sx, sy;
-    if (!world_to_map(m, x, y, sx, sy))
-        return false;
-    if (m.charmap[sx + sy * m.w] >= 250)
-        return false;
+    // Everything that decides which memory is read comes first, then the cost cell and the list bounds are
+    // requested together (two trips to memory in a row instead of three); the verdict logic follows in the
+    // reference's order.
+    uint32_t sx = 0, sy = 0;
+    const bool centre_on = world_to_map(m, x, y, sx, sy);
     F2 c[4];
     vehicle_corners(m, x, y, t, c);
     float bxmin = c[0].x, bxmax = c[0].x, bymin = c[0].y, bymax = c[0].y;
+    bool corners_on = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        if (!on_grid(m, c[i].x, c[i].y))
-            return false;
+        corners_on = corners_on && on_grid(m, c[i].x, c[i].y);
         bxmin = fminf_(bxmin, c[i].x), bxmax = fmaxf_(bxmax, c[i].x);
         bymin = fminf_(bymin, c[i].y), bymax = fmaxf_(bymax, c[i].y);
     }
-    uint32_t key = grid_key(m, c[0].x, c[0].y);
-    if (key >= m.w * m.h)
-        return true; // key absent from in_range_obstacle_map_: nothing to test
+    const uint32_t key = grid_key(m, c[0].x, c[0].y);
+    const bool listed = centre_on && corners_on && key < m.w * m.h;
     const uint32_t *off = m.seg_lmax > 0 ? m.pose_off : m.cell_off;
     const uint16_t *idx = m.seg_lmax > 0 ? m.pose_idx : m.cell_idx;
-    const uint32_t begin = off[key], e = off[key + 1];
+    const uint8_t cost = centre_on ? m.charmap[sx + sy * m.w] : (uint8_t)255;
+    const uint32_t begin = listed ? off[key] : 0u, e = listed ? off[key + 1] : 0u;
+    if (!centre_on || cost >= 250 || !corners_on)
+        return false;
+    if (!listed)
+        return true; // key absent from in_range_obstacle_map_: nothing to test
     typename QuadSrc::Cursor cur(idx, begin);
 #pragma unroll 1
     for (uint32_t k = begin; k < e; ++k)
@@ -584,13 +588,16 @@ HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, 
     const bool pruned = hy_fabsf(sx - ex) <= m.seg_lmax && hy_fabsf(sy - ey) <= m.seg_lmax;
     const uint32_t *off = pruned ? m.seg_off : m.cell_off;
     const uint16_t *idx = pruned ? m.seg_idx : m.cell_idx;
+    // the bounds of both lists are requested together; same key: same list, same verdicts
+    const bool walk0 = ks < cells, walk1 = ke < cells && ke != ks;
+    const uint32_t b0 = walk0 ? off[ks] : 0u, e0 = walk0 ? off[ks + 1] : 0u;
+    const uint32_t b1 = walk1 ? off[ke] : 0u, e1 = walk1 ? off[ke + 1] : 0u;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass)
     {
-        const uint32_t key = pass ? ke : ks;
-        if (key >= cells || (pass && ke == ks)) // same key: same list, same verdicts
+        const uint32_t begin = pass ? b1 : b0, end = pass ? e1 : e0;
+        if (begin >= end)
             continue;
-        const uint32_t begin = off[key], end = off[key + 1];
         typename QuadSrc::Cursor cur(idx, begin);
 #pragma unroll 1
         for (uint32_t k = begin; k < end; ++k)
