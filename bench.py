@@ -194,12 +194,23 @@ def main():
                 break
             except Exception:
                 traffic = None
+        l2 = None
+        # L2-side requests of the same kernel (profiles/collect_l2.sh), newest file
+        for lf in sorted((ROOT / "profiles").glob("r*_step_kernel_l2.json"), reverse=True):
+            try:
+                d = json.loads(lf.read_text())
+                l2 = {k: d[k] for k in ("l2_requests_per_launch", "l2_hit_rate", "l2_GBps_at_64B_per_request",
+                                        "l2_GBps_at_128B_per_request", "l2_peak_GBps")}
+                l2["source"] = f"profiles/{lf.name}"
+                break
+            except Exception:
+                l2 = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "kernel": "k_round", "avg_launch_us": avg_ms * 1e3,
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": launches_1,
-                    "note": "map, obstacle lists and tables are <= 30 MB and cache-resident: HBM fraction is low by "
-                            "construction; a launch lasts as long as its slowest workgroup's dependent chain (solve, reduce, "
-                            "interpolate, list walk). Bytes count every node a launch processed, including nodes expanded ahead "
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": launches_1, "l2": l2,
+                    "note": "map, obstacle lists and tables are <= 30 MB and cache-resident: HBM and L2 fractions are low by "
+                            "construction; a launch lasts as long as its slowest workgroup's dependent chain (solve, pick, "
+                            "interpolate, list walk), stretched by the launches that share the SIMDs. Bytes count every node a launch processed, including nodes expanded ahead "
                             "of time; `value` counts only expansions the search consumed"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(map_arr, starts, goals)
