@@ -15,6 +15,7 @@ cp gpurun_out/meas/prof/bench_kernel_stats.csv gpurun_out/meas/kernel_stats.csv
 rm -rf gpurun_out/meas/prof
 echo "kernel stats done"
 bash profiles/collect_traffic.sh
+bash profiles/collect_l2.sh
 # 4. the other configurations (bench.py --workload ...)
 timeout -k 10 300 python3 -u bench.py --workload footprint_checks > gpurun_out/meas/extra_footprint.json
 timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 1 > gpurun_out/meas/extra_table_pr1.json

@@ -5,6 +5,7 @@ cd "$(dirname "$0")/.."
 r=${1:-r01}
 cp gpurun_out/meas/kernel_stats.csv profiles/${r}_bench_kernel_stats.csv
 cp gpurun_out/pmc/step_kernel_traffic.json profiles/${r}_step_kernel_traffic.json
+cp gpurun_out/pmc/step_kernel_l2.json profiles/${r}_step_kernel_l2.json
 python3 - "$r" <<'PY'
 import json, sys
 r = sys.argv[1]
