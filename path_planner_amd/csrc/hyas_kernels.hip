@@ -665,21 +665,33 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         }
         if (CLOCKS)
             t_wave = mk1 = clock64() - c0; // candidates evaluated
-        int win = -1;
-        double best_total = rs::empty_path().total;
+        // The reference scans a family with a running minimum that starts at the family's bound and is replaced by
+        // strictly shorter candidates only: the family's entry is the first candidate that attains the family's
+        // minimum, and it is taken iff that minimum is below the bound.  The five minima do not depend on one another
+        // (five short chains instead of one of 44 steps); the bounds then chain through the families in order.
         constexpr int first[RS_NUM_FAMILIES + 1] = {0, 8, 16, 24, 40, 44}; // rs::family_first
+        double fam_min[RS_NUM_FAMILIES];
+        int fam_arg[RS_NUM_FAMILIES];
 #pragma unroll
         for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
         {
-            double lmin = rs::family_bound(fam, best_total);
+            double mn = lane_value(my_L, first[fam]);
+            int arg = first[fam];
 #pragma unroll
-            for (int c = first[fam]; c < first[fam + 1]; ++c)
+            for (int c = first[fam] + 1; c < first[fam + 1]; ++c)
             {
                 const double L = lane_value(my_L, c);
-                if (lmin > L)
-                    win = c, lmin = L, best_total = lane_value(mine.total, c);
+                if (mn > L)
+                    mn = L, arg = c;
             }
+            fam_min[fam] = mn, fam_arg[fam] = arg;
         }
+        int win = -1;
+        double best_total = rs::empty_path().total;
+#pragma unroll
+        for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
+            if (rs::family_bound(fam, best_total) > fam_min[fam])
+                win = fam_arg[fam], best_total = lane_value(mine.total, win);
         rs::Path best = rs::empty_path();
         if (win >= 0) // uniform
         {
