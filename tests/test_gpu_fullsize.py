@@ -166,3 +166,36 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
         assert res.tobytes() == base.tobytes(), env
         for i in range(0, 300, 7):
             assert np.array_equal(h.path(i), keep[i][0]) and np.array_equal(h.expanded(i), keep[i][1]), (env, i)
+
+
+def test_full_depth_searches_match_oracle(maze_ctx, oracle_built):
+    """Searches at the reference's full iteration limit (10 000), where one wrong verdict, cost bit or tie anywhere
+    along the way changes everything after it: result records, expansion order and paths against the CPU oracle,
+    one oracle context per thread."""
+    import os
+    import threading
+
+    h = maze_ctx
+    n = 96
+    S, G = make_queries(h.collision, n, 4242, 50, 50)
+    res = h.plan_batch(S, G)
+    assert (res["nodes_expanded"] > 9000).sum() > 20  # many of them run to the limit
+    got = [(h.path(i), h.expanded(i)) for i in range(n)]
+    T = max(1, min(16, len(os.sched_getaffinity(0))))
+    mp = orc.load_map("map_maze")
+    bad = []
+
+    def work(t):
+        o = orc.Oracle(orc.hot_path_params())
+        o.set_costmap(mp, build_table=True, nthreads=2)
+        for i in range(t, n, T):
+            r, path, exp = o.plan(S[i], G[i])
+            if r.tobytes() != res[i].tobytes() or not np.array_equal(exp, got[i][1]) or path.tobytes() != got[i][0].tobytes():
+                bad.append(i)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, sorted(bad)
