@@ -58,6 +58,10 @@ struct hyas_ctx
     void *h_scratch = nullptr;
     size_t h_scratch_bytes = 0;
     float *d_twod = nullptr;
+    // popped nodes of the search rounds: device memory the host stores into directly (large BAR), null if unavailable
+    void *d_nodes = nullptr;
+    size_t d_nodes_bytes = 0;
+    int nodes_tried = 0;
     size_t d_twod_bytes = 0;
 
     // results of the last hyas_plan_batch
@@ -93,6 +97,7 @@ int hip_fail(hyas_ctx *c, hipError_t e, const char *what);
 
 int ensure_scratch(hyas_ctx *c, size_t dev_bytes, size_t host_bytes);
 int ensure_twod(hyas_ctx *c, size_t bytes);
+int ensure_nodes(hyas_ctx *c, size_t bytes);
 void timer_begin(hyas_ctx *c);
 void timer_end(hyas_ctx *c, int which); // call after the stream has been synchronised
 void reset_timers(hyas_ctx *c);

@@ -714,6 +714,12 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         ds = (char *)c->d_scratch;
         char *hd = nullptr; // the pinned host block as the GPU addresses it
         HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
+        // the popped nodes go into device memory the host can store into, where there is such memory, else into the
+        // pinned host block; r_in: where the host writes them, k_in: where the kernel reads them
+        if ((rc = ensure_nodes(c, cn * KS * sizeof(StepIn))) != HYAS_OK)
+            return rc;
+        StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
+        const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
         HYAS_HIP(c, hipMemcpyAsync(c->d_twod, h_twod, cn * twod * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HYAS_HIP(c, hipMemcpyAsync(ds + o_goal, h_goal, cn * sizeof(hyas_goal), hipMemcpyHostToDevice, c->stream));
         HYAS_HIP(c, hipStreamSynchronize(c->stream));
@@ -829,7 +835,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 {
                     slot0[qi] = (uint32_t)slots;
                     for (int i = 0; i < Q[qi].nspec; ++i)
-                        h_in[g.s0 * KS + slots++] = stage[qi * KS + i];
+                        r_in[g.s0 * KS + slots++] = stage[qi * KS + i];
                     g.keep.push_back(qi);
                 }
             g.live.swap(g.keep); // queries that finished drop out
@@ -846,7 +852,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             const double t0 = now();
             size_t p_succ, p_len, p_ok, p_cnt;
             slice(g, p_succ, p_len, p_ok, p_cnt);
-            const StepIn *d_in = (const StepIn *)(hd + o_in) + s0 * KS;
+            const StepIn *d_in = k_in + s0 * KS;
+            if (c->d_nodes)
+                __builtin_ia32_sfence(); // the stores into device memory leave the write-combining buffers before the doorbell
             (void)hipEventRecord(ev[0], st);
             launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
                          (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
