@@ -87,6 +87,8 @@ int ensure_nodes(hyas_ctx *c, size_t bytes)
         return HYAS_OK;
     }
     c->d_nodes = p, c->d_nodes_bytes = bytes;
+    if (std::getenv("HYAS_TRACE"))
+        fprintf(stderr, "hyas: node block %p, %zu bytes of device memory\n", p, bytes);
     return HYAS_OK;
 }
 
