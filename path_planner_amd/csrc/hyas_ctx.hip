@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 #include <limits>
 #include <queue>
 
@@ -84,6 +86,31 @@ int ensure_nodes(hyas_ctx *c, size_t bytes)
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess)
     {
         (void)hipGetLastError();
+        return HYAS_OK;
+    }
+    // Is the block really mapped for this process, for reading and for writing?  Asked of the kernel, which answers
+    // EFAULT where a plain store would end the process: one byte from the block into a pipe, one byte from
+    // /dev/zero into the block, at both ends of the block.
+    bool mapped = false;
+    {
+        int fds[2] = {-1, -1};
+        const int zero = open("/dev/zero", O_RDONLY);
+        if (zero >= 0 && pipe(fds) == 0)
+        {
+            char *b = (char *)p;
+            mapped = write(fds[1], b, 1) == 1 && write(fds[1], b + bytes - 1, 1) == 1 && read(zero, b, 1) == 1 &&
+                     read(zero, b + bytes - 1, 1) == 1;
+        }
+        if (zero >= 0)
+            close(zero);
+        if (fds[0] >= 0)
+            close(fds[0]), close(fds[1]);
+    }
+    if (!mapped)
+    {
+        (void)hipFree(p);
+        if (std::getenv("HYAS_TRACE"))
+            fprintf(stderr, "hyas: device memory is not mapped for the host, nodes stay in pinned host memory\n");
         return HYAS_OK;
     }
     c->d_nodes = p, c->d_nodes_bytes = bytes;
