@@ -583,8 +583,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t chunk_cap = 8192;
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
-    size_t n_groups = 8; // query groups in flight at once: two per driver thread and hardware queue, so a driver
-                         // does the host part of one group while the kernel of its other group runs
+    // Query groups in flight at once, two per driver thread, so that a driver does the host part of one group while
+    // the kernel of its other group runs.  A process has four hardware queues and kernels that share one run one
+    // after the other: chunks of up to 2048 queries form four groups (a queue each, two drivers with half of the
+    // worker threads each); larger chunks eight groups and four drivers, where the host part outweighs the queueing.
+    size_t n_groups = 0; // 0: by chunk size
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
     // Nodes of one query expanded per round: its popped node plus the next best open-list entries, whose
@@ -611,12 +614,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
         auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-        const int ng = (int)std::max<size_t>(1, std::min<size_t>(n_groups, cn / 32 + 1));
+        const size_t want_groups = n_groups ? n_groups : (cn <= 2048 ? 4 : 8);
+        const int ng = (int)std::max<size_t>(1, std::min<size_t>(want_groups, cn / 32 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
         const int spec_k = spec_cfg;
         const size_t KS = (size_t)spec_k;
         const size_t o_in = take(cn * KS * sizeof(StepIn));
-        int max_drivers = 4; // 4 = hardware queues of a process
+        int max_drivers = std::max(1, ng / 2);
         if (const char *e = std::getenv("HYAS_DRIVERS"))
             max_drivers = std::max(1, std::atoi(e));
         const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
