@@ -607,6 +607,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     for (size_t base = 0; base < n; base += chunk_cap)
     {
         const size_t cn = std::min(chunk_cap, n - base);
+        const auto wall0 = std::chrono::steady_clock::now();
+        auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
         std::vector<Query> Q(cn);
 
         // staging layout (one pinned block, one device block)
@@ -913,6 +915,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
             }
         };
+        const double wall_setup = since(wall0);
         {
             std::vector<std::thread> drivers;
             for (int d = 1; d < n_drivers; ++d)
@@ -921,6 +924,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             for (auto &t : drivers)
                 t.join();
         }
+        const double wall_rounds = since(wall0) - wall_setup;
         double t_host = 0, t_launch = 0, t_wait = 0;
         for (int gi = 0; gi < ng; ++gi)
         {
@@ -933,8 +937,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         if (std::getenv("HYAS_TRACE"))
             fprintf(stderr,
                     "hyas rounds (%d groups, %d drivers x %d threads, %d nodes per query; slowest group): host push+pop %.3f s, launch %.3f s, "
-                    "wait %.3f s; %llu expansions answered ahead of time\n",
-                    ng, n_drivers, threads_per_driver, spec_k, t_host, t_launch, t_wait, (unsigned long long)spec_hits.load());
+                    "wait %.3f s; %llu expansions answered ahead of time; wall: set-up %.3f s, rounds %.3f s\n",
+                    ng, n_drivers, threads_per_driver, spec_k, t_host, t_launch, t_wait, (unsigned long long)spec_hits.load(), wall_setup,
+                    wall_rounds);
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
@@ -998,6 +1003,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             c->paths[base + i].swap(Q[i].path);
             c->expanded[base + i].swap(Q[i].expanded);
         }
+        if (std::getenv("HYAS_TRACE"))
+            fprintf(stderr, "hyas chunk of %zu queries: %.3f s in all, %.3f s after the rounds\n", cn, since(wall0),
+                    since(wall0) - wall_setup - wall_rounds);
     }
     return HYAS_OK;
 }
