@@ -740,6 +740,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             std::vector<uint32_t> live, keep;
             std::vector<size_t> bounds;
             size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
+            std::atomic<uint32_t> claim{0}; // nodes of the launch being assembled that the workers have claimed
             double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0;
             int64_t launches = 0;
             int rc = HYAS_OK;
@@ -780,6 +781,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             g.bounds.resize(nw + 1);
             for (int w = 0; w <= nw; ++w)
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
+            g.claim.store(0, std::memory_order_relaxed);
             gp.run_parts([&](int w) {
                 uint64_t hits = 0;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
@@ -833,19 +835,33 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
                 if (hits)
                     spec_hits.fetch_add(hits, std::memory_order_relaxed);
+                // This worker's nodes go into a range of the launch it claims in one step, copied by the thread
+                // that has just written them (one thread gathering everybody's nodes would fetch each line from
+                // another core's cache).  The order of the nodes within a launch is immaterial: results are found
+                // through slot0.
+                uint32_t mine = 0;
+                for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
+                    if (wants[g.live[k]])
+                        mine += (uint32_t)Q[g.live[k]].nspec;
+                uint32_t at = mine ? g.claim.fetch_add(mine, std::memory_order_relaxed) : 0;
+                for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
+                {
+                    const uint32_t qi = g.live[k];
+                    if (!wants[qi])
+                        continue;
+                    slot0[qi] = at;
+                    for (int i = 0; i < Q[qi].nspec; ++i)
+                        r_in[g.s0 * KS + at++] = stage[qi * KS + i];
+                }
+                if (c->d_nodes && mine)
+                    __builtin_ia32_sfence(); // stores into device memory leave this core's write-combining buffers
             });
             g.keep.clear();
-            size_t slots = 0;
             for (uint32_t qi : g.live)
                 if (wants[qi])
-                {
-                    slot0[qi] = (uint32_t)slots;
-                    for (int i = 0; i < Q[qi].nspec; ++i)
-                        r_in[g.s0 * KS + slots++] = stage[qi * KS + i];
                     g.keep.push_back(qi);
-                }
             g.live.swap(g.keep); // queries that finished drop out
-            g.ns = slots;
+            g.ns = g.claim.load(std::memory_order_relaxed);
             g.t_host += now() - t0;
             return g.ns != 0;
         };
