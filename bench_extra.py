@@ -50,7 +50,23 @@ def _barrier(torch, dist):
     torch.cuda.synchronize()
 
 
-def footprint_checks(args):
+def _newest_profile(pattern):
+    """The newest profiles/rNN_<pattern>.json (rocprofv3 counter summaries kept in the tree), or None."""
+    for f in sorted((ROOT / "profiles").glob(f"r*_{pattern}.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+            d["source"] = f"profiles/{f.name}"
+            return d
+        except Exception:
+            continue
+    return None
+
+
+# footprints of the footprint_checks workloads: (width, length) of the vehicle rectangle in cells
+FOOTPRINTS = {"in_tree": (0.18, 0.22), "car": (2.0, 4.5)}
+
+
+def footprint_checks(args, footprint="in_tree"):
     torch, dist, rank, local_rank, world = _dist_setup()
     from path_planner_amd import Hyas, default_params
     from path_planner_amd._lib import MODE_FOOTPRINT
@@ -58,10 +74,13 @@ def footprint_checks(args):
 
     W = H = 4096
     n = 10_000_000
+    fpw, fpl = FOOTPRINTS[footprint]
     grid = np.where(np.random.default_rng(1).random((H, W)) < 0.10, 254, 0).astype(np.uint8)
     rng = np.random.default_rng(2 + 7919 * rank)
     xyt = np.stack([rng.uniform(8, W - 8, n), rng.uniform(8, H - 8, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
-    ctx = Hyas(default_params(), device=local_rank)  # in-tree footprint constants: 7200 lists of at most 4 cells
+    # in_tree: the constants of include/constants.h (7200 lists of at most 4 cells); car: a 2 x 4.5 cell rectangle
+    # (lists of up to 64 cells, the capacity of Constants::config)
+    ctx = Hyas(default_params(fp_width=fpw, fp_length=fpl), device=local_rank)
     ctx.set_grid(grid)
     fp_len = ctx.footprint_table()[:, 0]
     d_xyt = torch.from_numpy(xyt).cuda()
@@ -85,16 +104,17 @@ def footprint_checks(args):
     it = (xyt[:, 2] / np.float32(2 * math.pi / 72)).astype(np.int64).clip(0, 71)
     ix = ((xyt[:, 0] - np.floor(xyt[:, 0])) * 10).astype(np.int64).clip(0, 9)
     iy = ((xyt[:, 1] - np.floor(xyt[:, 1])) * 10).astype(np.int64).clip(0, 9)
-    mean_len = float(fp_len[(iy * 10 + ix) * 72 + it].mean())
+    mean_len = float(np.minimum(fp_len, 64)[(iy * 10 + ix) * 72 + it].mean())  # the test reads at most 64 cells of a list
     bytes_per_launch = n * (13.0 + mean_len)
     avg_ms = kms / max(kl, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    prof = _newest_profile(f"footprint_{footprint}_traffic")
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, str(ROOT / "tests"))
         import orc
 
-        o = orc.Oracle(orc.default_params())
+        o = orc.Oracle(orc.default_params(fp_width=fpw, fp_length=fpl))
         o.set_grid(grid)
         m = 2_000_000
         t0 = time.perf_counter()
@@ -107,11 +127,13 @@ def footprint_checks(args):
         "metric": "footprint collision checks/sec", "value": checks / total_s, "unit": "checks/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
-        "config": {"workload": "4096x4096 grid, 10 % occupied, 10M footprint-list checks per GPU, in-tree 0.22x0.18 m footprint",
+        "config": {"workload": f"4096x4096 grid, 10 % occupied, 10M footprint-list checks per GPU, {footprint} footprint "
+                               f"({fpl} x {fpw} cells, lists of up to {int(fp_len.max())} cells)",
                    "free_fraction_rank0": free / n, "mean_cells_per_check": mean_len},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_collision_footprint", "avg_launch_us": avg_ms * 1e3,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "frac_of_achievable_6300": achieved / 6300.0,
+                     "traffic": prof.get("hbm_bytes_per_launch") if prof else None, "kernel": "k_collision_footprint_window",
+                     "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch, "counters": prof},
         "cpu_baseline": cpu,
     }
 
@@ -159,6 +181,18 @@ def rs_table(args):
         cpu = {"value": k1 * nx * ny / cs, "unit": "entries/s", "cores": 1, "kind": "port",
                "sample": f"{k1} of the {ns} heading slices on one thread ({cs:.2f} s)"}
     per_build = total_s / args.steps
+    kms, kl = ctx.kernel_ms(3)
+    # FP64 side: vector f64 operations per entry from the rocprofv3 counter pass (profiles/collect_table_f64.sh)
+    f64 = _newest_profile("table_rs_f64")
+    compute = None
+    if f64 and kl:
+        k_s = (kms / kl) * 1e-3  # one k_table_rs launch = this rank's slices
+        my_entries = entries / world if world > 1 else entries
+        tf = f64["f64_flops_per_entry"] * my_entries / k_s / 1e12
+        compute = {"bound": "valu_f64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                   "f64_flops_per_entry": f64["f64_flops_per_entry"], "kernel_ms": kms / kl, "source": f64["source"],
+                   "note": "peak = MI355X FP64 vector spec; flops = SQ f64 add + mul + 2 x fma + transcendental wave "
+                           "instructions x 64 lanes, i.e. issued lane slots: lanes switched off inside a closed form count"}
     return {
         "metric": "Reeds-Shepp heuristic table entries/sec", "value": entries / per_build, "unit": "entries/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * per_build, "higher_is_better": True,
@@ -167,27 +201,29 @@ def rs_table(args):
                    "seconds_build_gather_install_rank0": [p / args.steps for p in parts], "probe_costs": [float(v) for v in cost]},
         "roofline": {"bound": "hbm", "achieved": 4.0 * entries / (parts[0] / args.steps) / 1e9 if parts[0] > 0 else 0.0,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 4.0 * entries / (parts[0] / args.steps) / 1e9 / HBM_PEAK_GBS if parts[0] > 0 else 0.0,
-                     "traffic": None, "kernel": "k_table_rs",
-                     "note": "4 B stored per entry; the kernel is f64 ALU bound (44 closed-form candidates per entry), the HBM fraction is low by construction"},
+                     "traffic": None, "kernel": "k_table_rs", "compute": compute,
+                     "note": "4 B stored per entry; the kernel is f64 ALU bound (44 closed-form candidates per entry), the HBM fraction is low by construction; see roofline.compute"},
         "cpu_baseline": cpu,
     }
 
 
 def queries_large(args):
     torch, dist, rank, local_rank, world = _dist_setup()
-    sys.path.insert(0, str(ROOT / "tests"))
-    import orc  # map fixture loader only
     from path_planner_amd import Hyas, hot_path_params
-    from path_planner_amd.sharding import aggregate, make_queries, query_shard
+    from path_planner_amd.sharding import aggregate, load_map, make_queries, query_shard
 
+    scaling = args.scaling or "strong"
     total_q = args.queries if args.queries != 1024 else 65536
-    mp = orc.load_map("map_large")
+    mp = load_map("map_large")
     H, W = mp.shape
     ctx = Hyas(hot_path_params(), device=local_rank)
     ctx.set_costmap(mp, build_table=True)
-    starts, goals = make_queries(ctx.collision, total_q, 3, W, H)  # every rank draws the same batch, then takes its block
-    b, e = query_shard(total_q, rank, world)
-    starts, goals = starts[b:e], goals[b:e]
+    if scaling == "strong":
+        starts, goals = make_queries(ctx.collision, total_q, 3, W, H)  # every rank draws the same batch, then takes its block
+        b, e = query_shard(total_q, rank, world)
+        starts, goals = starts[b:e], goals[b:e]
+    else:
+        starts, goals = make_queries(ctx.collision, total_q, 3 + 7919 * rank, W, H)  # total_q queries per GPU
     for _ in range(args.warmup):
         ctx.plan_batch(starts[: min(len(starts), 2048)], goals[: min(len(goals), 2048)])
     _barrier(torch, dist)
@@ -206,8 +242,9 @@ def queries_large(args):
     return {
         "metric": "collision-checked node expansions/sec", "value": succ / total_s, "unit": "successors/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"map_large 180x60, {total_q} queries in contiguous blocks over {world} GPU(s), Reeds-Shepp shot every pop"},
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"map_large 180x60, {total_q} queries " + ("in contiguous blocks over" if scaling == "strong" else "on each of")
+                               + f" {world} GPU(s), Reeds-Shepp shot every pop"},
         "queries_per_s": nq / total_s, "nodes_expanded_per_s": expd / total_s, "status_counts_rank0": status,
         "round_kernel_avg_us_rank0": 1e3 * kms / max(kl, 1),
         "roofline": None, "cpu_baseline": None,
@@ -215,7 +252,8 @@ def queries_large(args):
 
 
 def run(args):
-    fn = {"footprint_checks": footprint_checks, "rs_table": rs_table, "queries_large": queries_large}[args.workload]
+    fn = {"footprint_checks": footprint_checks, "footprint_checks_car": lambda a: footprint_checks(a, "car"), "rs_table": rs_table,
+          "queries_large": queries_large}[args.workload]
     line = fn(args)
     if line is not None:
         print(json.dumps(line))

@@ -238,6 +238,10 @@ void hyas_reset_kernel_timers(hyas_ctx *ctx);
  * workgroup, 17 / 18 pose / swept-segment tests of one wave each, 19 sample
  * passes.  The same modes apply to hyas_shot_batch and hyas_expand_batch. */
 int hyas_set_stats(hyas_ctx *ctx, int enable);
+/* 1 if the last hyas_plan_batch handed its popped nodes to the GPU through device memory the host stores into
+ * directly (large-BAR GPUs), 0 if through pinned host memory (HYAS_NODES_IN_HOST_MEMORY=1 or no such mapping);
+ * no counterpart in the reference. */
+int hyas_nodes_in_device_memory(const hyas_ctx *ctx);
 int hyas_get_stats(hyas_ctx *ctx, uint64_t out[24]);
 
 #ifdef __cplusplus

@@ -1691,7 +1691,10 @@ struct Ctx
     };
 
     // src/hybrid_a_star.cpp:982-1018 + GetPath :41-311
-    void plan(const float s[3], const float g[3], hyas_result *res)
+    void plan(const float s[3], const float g[3], hyas_result *res) { planInto(s, g, res, last_path, last_expanded); }
+    // The same search with its outputs in caller-owned vectors: touches no member, so several threads may plan on
+    // one context (the map and the table are only read).
+    void planInto(const float s[3], const float g[3], hyas_result *res, std::vector<float> &last_path, std::vector<int32_t> &last_expanded)
     {
         std::memset(res, 0, sizeof(*res));
         last_path.clear();
@@ -2074,6 +2077,22 @@ int orc_plan(void *h, const float *start, const float *goal, hyas_result *res)
     ((Ctx *)h)->plan(start, goal, res);
     return 0;
 }
+// Thread-safe form of orc_plan + orc_get_path + orc_get_expanded: outputs go to the caller's buffers
+// (path_n / exp_n receive the full lengths; at most the caps are copied).
+int orc_plan_r(void *h, const float *start, const float *goal, hyas_result *res, float *path_xyt, size_t path_cap, int32_t *path_n,
+               int32_t *exp_idx, size_t exp_cap, int32_t *exp_n)
+{
+    std::vector<float> path;
+    std::vector<int32_t> expanded;
+    ((Ctx *)h)->planInto(start, goal, res, path, expanded);
+    *path_n = (int32_t)(path.size() / 3), *exp_n = (int32_t)expanded.size();
+    if (path_xyt)
+        std::memcpy(path_xyt, path.data(), std::min(path_cap * 3, path.size()) * sizeof(float));
+    if (exp_idx)
+        std::memcpy(exp_idx, expanded.data(), std::min(exp_cap, expanded.size()) * sizeof(int32_t));
+    return 0;
+}
+
 int orc_get_path(void *h, float *xyt, size_t cap)
 {
     Ctx *c = (Ctx *)h;

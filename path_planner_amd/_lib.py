@@ -67,7 +67,7 @@ EXPORTS = [
     "hyas_collision_batch_dev", "hyas_footprint_table", "hyas_expand_batch", "hyas_num_successors",
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
-    "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats",
+    "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats", "hyas_nodes_in_device_memory",
 ]
 
 _lib = None
@@ -130,6 +130,7 @@ def load_library():
     L.hyas_reset_kernel_timers.argtypes = [C.c_void_p]
     L.hyas_set_stats.argtypes = [C.c_void_p, C.c_int]
     L.hyas_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.hyas_nodes_in_device_memory.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -322,6 +323,9 @@ class Hyas:
 
     def reset_kernel_timers(self):
         self.L.hyas_reset_kernel_timers(self.h)
+
+    def nodes_in_device_memory(self):
+        return self.L.hyas_nodes_in_device_memory(self.h) == 1
 
     def set_stats(self, mode):
         """0 off, 1 work counters, 2 phase clocks."""

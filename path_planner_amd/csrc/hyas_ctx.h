@@ -10,6 +10,11 @@
 
 #define HYAS_MAX_GROUPS 16
 
+namespace hyas
+{
+struct SearchPools;
+}
+
 struct hyas_ctx
 {
     hyas_params P{};
@@ -44,6 +49,7 @@ struct hyas_ctx
     int32_t *d_fp = nullptr;
     uint64_t *d_occ_tiles = nullptr;
     hyas::FpPack *d_fp_pack = nullptr;
+    uint32_t *d_fp_win = nullptr;
     float *d_table = nullptr;
     float *d_tab_xs = nullptr, *d_tab_ys = nullptr, *d_tab_ts = nullptr;
     double *d_seg = nullptr;
@@ -63,6 +69,14 @@ struct hyas_ctx
     size_t d_nodes_bytes = 0;
     int nodes_tried = 0;
     size_t d_twod_bytes = 0;
+    // workspace of the 2D flood kernel (cell coordinates, queue spill, cell state of maps too large for LDS)
+    void *d_flood_ws = nullptr;
+    size_t d_flood_ws_bytes = 0;
+    // sampled curves of the queries an analytic shot closed (hyas_plan_batch)
+    float *d_pts = nullptr;
+    size_t d_pts_bytes = 0;
+    // host worker threads of the search driver, kept between calls (created on first use)
+    hyas::SearchPools *pools = nullptr;
 
     // results of the last hyas_plan_batch
     std::vector<std::vector<float>> paths;
@@ -98,11 +112,15 @@ int hip_fail(hyas_ctx *c, hipError_t e, const char *what);
 int ensure_scratch(hyas_ctx *c, size_t dev_bytes, size_t host_bytes);
 int ensure_twod(hyas_ctx *c, size_t bytes);
 int ensure_nodes(hyas_ctx *c, size_t bytes);
+int ensure_buffer(hyas_ctx *c, void **buf, size_t *have, size_t bytes); // device buffer that only grows
+void free_search_pools(hyas_ctx *c);
+// 2D flood of `nq` queries on the GPU (see k_flood): poses6_dev / qlist_dev / twod_dev / start_cost_dev are device
+// pointers; launches on `s` and returns without waiting
+int flood_dev(hyas_ctx *c, const float *poses6_dev, const uint32_t *qlist_dev, uint32_t nq, float *twod_dev, float *start_cost_dev,
+              hipStream_t s);
 void timer_begin(hyas_ctx *c);
 void timer_end(hyas_ctx *c, int which); // call after the stream has been synchronised
 void reset_timers(hyas_ctx *c);
 
-// host restatements used by the search driver (hyas_host.cpp)
-void flood_2d(const hyas_ctx *c, float gx, float gy, float *out /* twod_size floats */);
 int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out);
 } // namespace hyas

@@ -11,7 +11,6 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <limits>
-#include <queue>
 
 using namespace hyas;
 
@@ -63,18 +62,54 @@ int ensure_twod(hyas_ctx *c, size_t bytes)
     return HYAS_OK;
 }
 
+int ensure_buffer(hyas_ctx *c, void **buf, size_t *have, size_t bytes)
+{
+    if (bytes <= *have)
+        return HYAS_OK;
+    if (*buf)
+        HYAS_HIP(c, hipFree(*buf));
+    *buf = nullptr, *have = 0;
+    const size_t want = bytes + bytes / 4;
+    HYAS_HIP(c, hipMalloc(buf, want));
+    *have = want;
+    return HYAS_OK;
+}
+
+int flood_dev(hyas_ctx *c, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod, float *start_cost, hipStream_t s)
+{
+    if (!nq)
+        return HYAS_OK;
+    int cap_override = 0;
+    if (const char *e = std::getenv("HYAS_FLOOD_HEAP")) // test knob: a tiny queue in LDS sends the rest through the spill area
+        cap_override = std::max(1, std::atoi(e));
+    const FloodPlan fp = plan_flood((uint32_t)c->twod_size, nq, cap_override);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_xy = 0, o_heap = up(fp.ws_xy_bytes), o_g = o_heap + up(fp.ws_heap_bytes), o_ps = o_g + up(fp.ws_g_bytes),
+                 total = o_ps + up(fp.ws_ps_bytes);
+    int rc = ensure_buffer(c, &c->d_flood_ws, &c->d_flood_ws_bytes, total);
+    if (rc != HYAS_OK)
+        return rc;
+    char *ws = (char *)c->d_flood_ws;
+    hipError_t e = launch_flood(c->dm, fp, poses6, qlist, nq, twod, start_cost, ws + o_xy, ws + o_heap, fp.ws_g_bytes ? ws + o_g : nullptr,
+                                fp.ws_ps_bytes ? ws + o_ps : nullptr, s);
+    if (e != hipSuccess)
+        return hip_fail(c, e, "2D flood launch");
+    return HYAS_OK;
+}
+
 // Device memory for the round kernel's input that the host writes with plain stores: fine-grained (coherent)
 // device memory on a GPU whose whole memory is visible to the CPU.  The kernel then reads its node from local
 // memory (0.5 us) instead of fetching it from host memory over PCIe (1.5-2 us).  Leaves d_nodes null where that
 // is not possible; the caller then keeps the nodes in pinned host memory.
 int ensure_nodes(hyas_ctx *c, size_t bytes)
 {
-    if (bytes <= c->d_nodes_bytes)
+    const bool host_only = std::getenv("HYAS_NODES_IN_HOST_MEMORY") != nullptr;
+    if (!host_only && c->d_nodes && bytes <= c->d_nodes_bytes)
         return HYAS_OK;
     if (c->d_nodes)
         (void)hipFree(c->d_nodes);
     c->d_nodes = nullptr, c->d_nodes_bytes = 0;
-    if (std::getenv("HYAS_NODES_IN_HOST_MEMORY"))
+    if (host_only)
         return HYAS_OK;
     int large_bar = 0;
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) != hipSuccess || large_bar != 1)
@@ -351,79 +386,6 @@ static void build(const hyas_params &P, std::vector<int32_t> &out)
 }
 } // namespace fpt
 
-// ------------------------------------------------------- 2D cost-to-goal
-// HybridAStar::BuildAStarCostMap, src/hybrid_a_star.cpp:1020-1074, with
-// AStar::CreateSuccessor(pred, 8) (src/a_star.cpp:214-277; step = resolution,
-// :340-346) and AStar::UpdateCostSoFar (:281-288).  The open queue keeps the
-// priority a cell had when it was first pushed (the parent's cost) and its
-// comparator is `>=` (include/hybrid_a_star.h:45-53), so the very same
-// std::priority_queue is used here to reproduce the pop order.
-struct FloodCmp
-{
-    bool operator()(const std::pair<int, double> &l, const std::pair<int, double> &r) const { return l.second >= r.second; }
-};
-struct FloodCell
-{
-    float x, y, g, px, py;
-    uint8_t state; // 0 unseen, 1 open (no parent), 2 open (has parent)
-};
-
-void flood_2d(const hyas_ctx *c, float gx, float gy, float *out)
-{
-    const DevMap &m = c->dm; // host code only touches its scalar members
-    const size_t N = c->twod_size;
-    std::fill(out, out + N, -1.f);
-    std::vector<FloodCell> cells(N);
-    for (auto &cl : cells)
-        cl.state = 0;
-    std::priority_queue<std::pair<int, double>, std::vector<std::pair<int, double>>, FloodCmp> pq;
-    auto in_range = [&](int id) { return id >= 0 && (size_t)id < N; };
-    int gid = idx_2d(m, gx, gy);
-    if (!in_range(gid))
-        return;
-    cells[gid] = FloodCell{gx, gy, 0.f, 0.f, 0.f, 1};
-    pq.emplace(gid, 0.0);
-    const float step = m.res_f;
-    const float delta[3] = {-step, 0, step};
-    while (!pq.empty())
-    {
-        const int id = pq.top().first;
-        pq.pop();
-        FloodCell &cur = cells[id];
-        if (cur.state == 2)
-            cur.g = cur.g + normf(sub(f2(cur.x, cur.y), f2(cur.px, cur.py)));
-        const int cid = idx_2d(m, cur.x, cur.y);
-        if (in_range(cid) && out[cid] < 0)
-            out[cid] = cur.g;
-        const float cx = cur.x, cy = cur.y, cg = cur.g;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j)
-            {
-                if (delta[i] == 0 && delta[j] == 0)
-                    continue;
-                const float xs = cx + delta[i], ys = cy + delta[j];
-                if (!on_grid(m, xs, ys))
-                    continue;
-                const int nid = idx_2d(m, xs, ys);
-                if (!in_range(nid))
-                    continue;
-                if (out[nid] >= 0)
-                    continue;
-                FloodCell &nb = cells[nid];
-                if (nb.state != 0)
-                {
-                    if (nb.g > cg)
-                        nb.g = cg, nb.px = cx, nb.py = cy, nb.state = 2;
-                }
-                else
-                {
-                    nb = FloodCell{xs, ys, cg, cx, cy, 2};
-                    pq.emplace(nid, (double)cg);
-                }
-            }
-    }
-}
-
 static void set_resolution(DevMap &m, double res, double ox, double oy)
 {
     m.res = res, m.ox = ox, m.oy = oy;
@@ -438,14 +400,16 @@ static void set_resolution(DevMap &m, double res, double ox, double oy)
 static void free_map(hyas_ctx *c)
 {
     void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
-                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack, c->d_seg_db};
+                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack, c->d_seg_db, c->d_fp_win};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
     c->d_charmap = nullptr, c->d_quads = nullptr, c->d_cell_off = nullptr, c->d_cell_idx = nullptr, c->d_fp = nullptr;
     c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
     c->d_pose_off = c->d_seg_off = nullptr, c->d_pose_idx = c->d_seg_idx = nullptr;
-    c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr, c->d_seg_db = nullptr;
+    c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr, c->d_seg_db = nullptr, c->d_fp_win = nullptr;
+    c->tab_xs.clear(), c->tab_ys.clear(), c->tab_ts.clear();
+    c->table_size = 0, c->twod_size = 0, c->seg_cap = 0;
     c->have_map = c->have_table = false;
 }
 
@@ -467,14 +431,55 @@ static int upload_footprint_forms(hyas_ctx *c)
     DevMap &m = c->dm;
     const uint32_t w = c->w, h = c->h, tx = (w + 7) / 8, ty = (h + 7) / 8;
     std::vector<uint64_t> tiles((size_t)tx * ty, 0);
-    for (uint32_t y = 0; y < h; ++y)
-        for (uint32_t x = 0; x < w; ++x)
-            if (c->charmap[(size_t)y * w + x] >= 250)
+    for (uint32_t y = 0; y < ty * 8; ++y)
+        for (uint32_t x = 0; x < tx * 8; ++x)
+            if (x >= w || y >= h || c->charmap[(size_t)y * w + x] >= 250)
                 tiles[(size_t)(y >> 3) * tx + (x >> 3)] |= 1ull << (((y & 7) << 3) | (x & 7));
     int rc = upload(c, c->d_occ_tiles, tiles);
     if (rc != HYAS_OK)
         return rc;
-    m.occ_tiles = c->d_occ_tiles, m.tiles_x = tx;
+    m.occ_tiles = c->d_occ_tiles, m.tiles_x = tx, m.tiles_y = ty;
+    // window bitmaps: the box of Lookup::collisionLookup (include/lookup.h:56-60) is bb cells wide and the pose's
+    // cell sits at box cell ((int)c.x, (int)c.y) with c = bb / 2 + sub-cell offset (:87-92, :262-263)
+    m.fp_win = nullptr, m.fp_bb = 0, m.fp_win_words = 0;
+    {
+        const hyas_params &P = c->P;
+        const int bb = (int)std::ceil((std::sqrt(P.fp_width * P.fp_width + P.fp_length * P.fp_length) + 4) / P.fp_cell_size);
+        const int pr = P.position_resolution, headings = P.headings;
+        const size_t n_entries = c->fp.size() / 129;
+        const int words = (bb * bb + 2 + 31) / 32;
+        bool ok = bb >= 1 && bb <= 9 && n_entries == (size_t)pr * pr * headings && n_entries * words * 4 <= 150 * 1024;
+        std::vector<uint32_t> win(ok ? n_entries * words : 0, 0u);
+        for (size_t e = 0; e < n_entries && ok; ++e)
+        {
+            const int q = (int)(e / headings);
+            const int cxi = (int)((float)bb / 2 + 1.f / pr * (q % pr)), cyi = (int)((float)bb / 2 + 1.f / pr * (q / pr));
+            if (cxi - bb / 2 < 0 || cxi - bb / 2 > 1 || cyi - bb / 2 < 0 || cyi - bb / 2 > 1)
+                ok = false;
+            const int32_t *src = &c->fp[e * 129];
+            uint32_t *dst = &win[e * words];
+            const int len = std::min(src[0], 64);
+            for (int k = 0; k < len && ok; ++k)
+            {
+                const int j = src[1 + 2 * k] + cxi, i = src[2 + 2 * k] + cyi;
+                if (j < 0 || j >= bb || i < 0 || i >= bb)
+                    ok = false;
+                else
+                    dst[(i * bb + j) >> 5] |= 1u << ((i * bb + j) & 31);
+            }
+            const int fb = bb * bb;
+            if (ok && cxi - bb / 2)
+                dst[fb >> 5] |= 1u << (fb & 31);
+            if (ok && cyi - bb / 2)
+                dst[(fb + 1) >> 5] |= 1u << ((fb + 1) & 31);
+        }
+        if (ok && n_entries && !std::getenv("HYAS_NO_FP_WINDOW"))
+        {
+            if ((rc = upload(c, c->d_fp_win, win)) != HYAS_OK)
+                return rc;
+            m.fp_win = c->d_fp_win, m.fp_bb = bb, m.fp_win_words = words;
+        }
+    }
     const size_t entries = c->fp.size() / 129;
     std::vector<FpPack> pack(entries);
     bool fits = entries * sizeof(FpPack) <= 150 * 1024; // the kernel keeps the whole table in LDS
@@ -599,8 +604,15 @@ void hyas_destroy(hyas_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    free_search_pools(c);
+    for (int g = 0; g < HYAS_MAX_GROUPS; ++g) // round_stream[0] is c->stream
+        if (c->round_stream[g])
+            (void)hipStreamSynchronize(c->round_stream[g]);
     free_map(c);
+    if (c->d_flood_ws)
+        (void)hipFree(c->d_flood_ws);
+    if (c->d_pts)
+        (void)hipFree(c->d_pts);
     if (c->d_scratch)
         (void)hipFree(c->d_scratch);
     if (c->h_scratch)
@@ -655,8 +667,10 @@ static void fill_motion_set(hyas_ctx *c)
 
 int hyas_table_dims(const hyas_ctx *c, int32_t *nx, int32_t *ny, int32_t *ns)
 {
-    if (!c || !c->have_map)
+    if (!c || !c->have_map || c->grid_only)
         return HYAS_ESTATE;
+    if (!nx || !ny || !ns)
+        return HYAS_EINVAL;
     *nx = (int32_t)c->tab_xs.size(), *ny = (int32_t)c->tab_ys.size(), *ns = (int32_t)c->tab_ts.size();
     return HYAS_OK;
 }
@@ -665,6 +679,8 @@ int hyas_table_build_dev(hyas_ctx *c, int curve, int k0, int k1, float *out_dev)
 {
     if (!c || !c->have_map)
         return HYAS_ESTATE;
+    if (c->grid_only)
+        return c->fail(HYAS_ESTATE, "the heuristic table needs hyas_set_costmap, not hyas_set_grid");
     if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
         return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
     if (k0 < 0 || k1 > (int)c->tab_ts.size() || k0 > k1 || !out_dev)
@@ -687,6 +703,10 @@ int hyas_table_install_dev(hyas_ctx *c, int curve, const float *raw_dev)
 {
     if (!c || !c->have_map)
         return HYAS_ESTATE;
+    if (c->grid_only || !c->d_table)
+        return c->fail(HYAS_ESTATE, "the heuristic table needs hyas_set_costmap, not hyas_set_grid");
+    if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
+        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
     if (!raw_dev)
         return c->fail(HYAS_EINVAL, "null table");
     HYAS_HIP(c, hipSetDevice(c->device));
@@ -748,20 +768,6 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     c->cell_idx.clear();
     if (!c->quads.empty())
     {
-        const size_t nflag = xs.size() * ys.size() * c->quads.size();
-        float *d_xs = nullptr, *d_ys = nullptr;
-        uint8_t *d_flags = nullptr;
-        if ((rc = upload(c, d_xs, xs)) != HYAS_OK || (rc = upload(c, d_ys, ys)) != HYAS_OK)
-            return rc;
-        HYAS_HIP(c, hipMalloc((void **)&d_flags, nflag));
-        launch_in_range(c->d_quads, (uint32_t)c->quads.size(), d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(),
-                        c->P.obstacle_detection_range, d_flags, c->stream);
-        std::vector<uint8_t> flags(nflag);
-        hipError_t e = hipMemcpyAsync(flags.data(), d_flags, nflag, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(c->stream);
-        (void)hipFree(d_xs), (void)hipFree(d_ys), (void)hipFree(d_flags);
-        HYAS_HIP(c, e);
         // in_range_obstacle_map_.emplace(key, list): the first loop position
         // that maps to a key keeps it (src/collisiondetection.cpp:345)
         std::vector<int64_t> owner(cells, -1);
@@ -772,16 +778,61 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
                 if (key < cells && owner[key] < 0)
                     owner[key] = (int64_t)(i * ys.size() + j);
             }
+        // The range flags (one byte per cell corner and quad) are produced on the GPU in tiles of whole x columns of
+        // at most 64 MiB, so that the staging does not grow with cells x quads.
+        const size_t nq = c->quads.size(), per_col = ys.size() * nq;
+        const size_t cols_per_tile = std::max<size_t>(1, std::min<size_t>(xs.size(), ((size_t)64 << 20) / std::max<size_t>(per_col, 1)));
+        float *d_xs = nullptr, *d_ys = nullptr;
+        uint8_t *d_flags = nullptr;
+        std::vector<uint8_t> flags(cols_per_tile * per_col);
+        // per-key lists, filled tile by tile: lists[key] is written once, by the key's owner position
+        std::vector<std::vector<uint16_t>> lists(cells);
+        std::vector<std::vector<uint32_t>> keys_of_col(xs.size());
+        for (size_t key = 0; key < cells; ++key)
+            if (owner[key] >= 0)
+                keys_of_col[(size_t)owner[key] / ys.size()].push_back((uint32_t)key);
+        hipError_t e = hipSuccess;
+        rc = upload(c, d_xs, xs);
+        if (rc == HYAS_OK)
+            rc = upload(c, d_ys, ys);
+        if (rc == HYAS_OK && (e = hipMalloc((void **)&d_flags, flags.size())) != hipSuccess)
+            rc = hip_fail(c, e, "hipMalloc(range flags)");
+        for (size_t i0 = 0; rc == HYAS_OK && i0 < xs.size(); i0 += cols_per_tile)
+        {
+            const size_t ni = std::min(cols_per_tile, xs.size() - i0);
+            launch_in_range(c->d_quads, (uint32_t)nq, d_xs + i0, (uint32_t)ni, d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range,
+                            d_flags, c->stream);
+            e = hipGetLastError();
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(flags.data(), d_flags, ni * per_col, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess)
+            {
+                rc = hip_fail(c, e, "range flags");
+                break;
+            }
+            for (size_t i = i0; i < i0 + ni; ++i)
+                for (uint32_t key : keys_of_col[i])
+                {
+                    const uint8_t *f = &flags[((size_t)owner[key] - i0 * ys.size()) * nq];
+                    for (size_t q = 0; q < nq; ++q)
+                        if (f[q])
+                            lists[key].push_back((uint16_t)q);
+                }
+        }
+        if (d_xs)
+            (void)hipFree(d_xs);
+        if (d_ys)
+            (void)hipFree(d_ys);
+        if (d_flags)
+            (void)hipFree(d_flags);
+        if (rc != HYAS_OK)
+            return rc;
         for (size_t key = 0; key < cells; ++key)
         {
             c->cell_off[key] = (uint32_t)c->cell_idx.size();
-            if (owner[key] >= 0)
-            {
-                const uint8_t *f = &flags[(size_t)owner[key] * c->quads.size()];
-                for (size_t q = 0; q < c->quads.size(); ++q)
-                    if (f[q])
-                        c->cell_idx.push_back((uint16_t)q);
-            }
+            c->cell_idx.insert(c->cell_idx.end(), lists[key].begin(), lists[key].end());
         }
         c->cell_off[cells] = (uint32_t)c->cell_idx.size();
     }
@@ -997,7 +1048,20 @@ int hyas_flood(hyas_ctx *c, const hyas_goal *goal, float *out)
         return HYAS_ESTATE;
     if (!goal || !out)
         return c->fail(HYAS_EINVAL, "null buffer");
-    flood_2d(c, goal->x, goal->y, out);
+    HYAS_HIP(c, hipSetDevice(c->device));
+    const size_t N = c->twod_size;
+    int rc = ensure_twod(c, N * sizeof(float) + 256);
+    if (rc != HYAS_OK)
+        return rc;
+    // one query {start (unused), goal}; the poses sit behind the cost map in the same buffer
+    float *d_pose = (float *)((char *)c->d_twod + ((N * sizeof(float) + 63) & ~(size_t)63));
+    const float pose[6] = {0, 0, 0, goal->x, goal->y, goal->t};
+    HYAS_HIP(c, hipMemcpyAsync(d_pose, pose, sizeof pose, hipMemcpyHostToDevice, c->stream));
+    rc = flood_dev(c, d_pose, nullptr, 1, c->d_twod, nullptr, c->stream);
+    if (rc != HYAS_OK)
+        return rc;
+    HYAS_HIP(c, hipMemcpyAsync(out, c->d_twod, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
     return HYAS_OK;
 }
 
@@ -1124,6 +1188,8 @@ int hyas_set_stats(hyas_ctx *c, int enable)
     return HYAS_OK;
 }
 
+int hyas_nodes_in_device_memory(const hyas_ctx *c) { return c ? (c->d_nodes ? 1 : 0) : HYAS_EINVAL; }
+
 int hyas_get_stats(hyas_ctx *c, uint64_t out[24])
 {
     if (!c || !out)
@@ -1136,7 +1202,7 @@ int hyas_get_stats(hyas_ctx *c, uint64_t out[24])
 // obstacle polygons (8 floats each) and per-key list sizes, for tests
 int hyas_get_obstacles(const hyas_ctx *c, float *out, size_t cap)
 {
-    if (!c || !c->have_map)
+    if (!c || !c->have_map || c->grid_only)
         return HYAS_ESTATE;
     size_t n = std::min(cap, c->quads.size());
     for (size_t i = 0; i < n && out; ++i)
@@ -1146,7 +1212,7 @@ int hyas_get_obstacles(const hyas_ctx *c, float *out, size_t cap)
 }
 int hyas_in_range_count(const hyas_ctx *c, uint32_t key)
 {
-    if (!c || !c->have_map || key >= (uint64_t)c->w * c->h)
+    if (!c || !c->have_map || c->grid_only || key >= (uint64_t)c->w * c->h || (size_t)key + 1 >= c->cell_off.size())
         return -1;
     return (int)(c->cell_off[key + 1] - c->cell_off[key]);
 }

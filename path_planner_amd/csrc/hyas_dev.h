@@ -104,10 +104,17 @@ struct DevMap
     const int32_t *fp;   // entries x {len, pos[64][2]}
     // the same data in the form the batched footprint kernel gathers from:
     //  occ_tiles: one bit per cell (1: cost >= 250), 8x8 cells per 64-bit word, word (Y>>3)*tiles_x + (X>>3),
-    //             bit ((Y&7)<<3)|(X&7): 1/8 of the byte grid, so a 4096x4096 map stays in one L2
+    //             bit ((Y&7)<<3)|(X&7): 1/8 of the byte grid, so a 4096x4096 map stays in one L2; bits of cells
+    //             beyond the grid's last row / column are 1 (off the grid collides)
     //  fp_pack:   16 bytes per list {len, (dx, dy) as int8 x 7}; null when a list is longer or an offset wider
+    //  fp_win:    every list as a bitmap over the fp_bb x fp_bb cell box it was rasterised in (bit i * fp_bb + j =
+    //             cell (j, i) of the box), fp_win_words 32-bit words per list; the two bits after the bitmap say
+    //             whether the box sits fp_bb / 2 or fp_bb / 2 + 1 cells left of / below the pose's cell; null when
+    //             the box is wider than 9 cells (a box of up to 9 cells spans at most 2 x 2 bit tiles)
     const uint64_t *occ_tiles;
-    uint32_t tiles_x;
+    uint32_t tiles_x, tiles_y;
+    const uint32_t *fp_win;
+    int32_t fp_bb, fp_win_words;
     const FpPack *fp_pack;
     uint32_t fp_entries;
     int32_t fp_max_len;

@@ -37,4 +37,18 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
 void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                       const uint32_t *offsets, float *out, uint32_t *n_out, hipStream_t s);
 
+
+// Launch geometry and workspace sizes of the 2D flood kernel for a map of n_cells (= twod_size) cells.
+struct FloodPlan
+{
+    uint32_t n_cells, cells_pad, heap_cap, grid;
+    bool narrow, cells_in_lds;
+    size_t lds_bytes, ws_xy_bytes, ws_heap_bytes, ws_g_bytes, ws_ps_bytes;
+};
+FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override);
+// poses6: n x {start x, y, t, goal x, y, t}; qlist: which queries to flood (null: 0..nq-1); twod: [query][n_cells];
+// start_cost (optional): the cost at each query's start cell, -1 if the flood never closed it.
+hipError_t launch_flood(const DevMap &m, const FloodPlan &fp, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod,
+                        float *start_cost, void *ws_xy, void *ws_heap, void *ws_g, void *ws_ps, hipStream_t s);
+
 } // namespace hyas

@@ -11,9 +11,11 @@
 
 #include "hyas_dev.h"
 #include <algorithm>
+#include <cstdlib>
 
 #include "hyas_kernels.h"
 #include "hyas_dubins.h"
+#include "hyas_flood.h"
 #include "hyas_rs.h"
 
 namespace hyas
@@ -133,6 +135,146 @@ __global__ void __launch_bounds__(1024) k_collision_footprint_tiles(DevMap m, co
             v |= free_ ? 1u << (8 * k) : 0u;
         }
         *reinterpret_cast<uint32_t *>(out + 4 * g) = v;
+    }
+    // the last n % 4 poses
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+    {
+        const size_t i = (n & ~(size_t)3) + threadIdx.x;
+        out[i] = footprint_free(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]) ? 1 : 0;
+    }
+}
+
+// Footprint-list mode over the bit-tile grid with every list held in LDS as a bitmap over the box it was rasterised
+// in (DevMap::fp_win).  A pose's box covers at most 2 x 2 bit tiles: the tiles its bitmap touches are fetched (one
+// 8-byte gather each, usually a single one: the lists are short and an 8 x 8 tile is wide), the box's rows are cut
+// out of them and ANDed with the bitmap.  A listed cell off the grid reads as occupied (tile bits beyond the grid
+// are 1, tiles beyond the grid all ones), which is the verdict the per-cell test gives.
+// Four poses per thread and iteration: three 16-byte pose loads, requested one iteration ahead, one 4-byte store.
+template <int BB>
+__global__ void __launch_bounds__(BB <= 5 ? 512 : 1024) k_collision_footprint_window(DevMap m, const float *__restrict__ xyt, size_t n,
+                                                                                     uint8_t *__restrict__ out)
+{
+    constexpr int WORDS = (BB * BB + 2 + 31) / 32;
+    constexpr uint32_t ROWMASK = (1u << BB) - 1u;
+    extern __shared__ uint32_t s_win[];
+    {
+        const uint32_t total = m.fp_entries * WORDS;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
+            s_win[i] = m.fp_win[i];
+    }
+    __syncthreads();
+    const int pr = m.pr;
+    const size_t groups = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(xyt);
+    f32x4 a = {0, 0, 0, 0}, b = a, c = a;
+    if (g < groups)
+    {
+        a = __builtin_nontemporal_load(src + 3 * g);
+        b = __builtin_nontemporal_load(src + 3 * g + 1);
+        c = __builtin_nontemporal_load(src + 3 * g + 2);
+    }
+    while (g < groups)
+    {
+        const size_t gn = g + stride;
+        f32x4 na = {0, 0, 0, 0}, nb = na, nc = na;
+        if (gn < groups)
+        {
+            na = __builtin_nontemporal_load(src + 3 * gn);
+            nb = __builtin_nontemporal_load(src + 3 * gn + 1);
+            nc = __builtin_nontemporal_load(src + 3 * gn + 2);
+        }
+        const float px[4] = {a.x, a.w, b.z, c.y}, py[4] = {a.y, b.x, b.w, c.z}, pt[4] = {a.z, b.y, c.x, c.w};
+        uint32_t win[4][WORDS];
+        uint64_t tile[4][4];
+        int sx[4], sy[4];
+        bool in_table[4];
+        // pass 1: bitmaps from LDS, tile gathers requested
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const float x = px[k], y = py[k];
+            // |x|, |y| < 2^31 (false for NaN): there (long)x == (int)x, so the fraction needs no 64-bit conversion.
+            // Anything else is off the grid for the reference as well (its int conversion yields INT_MIN).
+            const bool sane = hy_fabsf(x) < 2147483648.f && hy_fabsf(y) < 2147483648.f && pt[k] == pt[k];
+            const int X = (int)x, Y = (int)y;
+            int iX = (int)((x - (float)X) * pr);
+            iX = iX > 0 ? iX : 0;
+            int iY = (int)((y - (float)Y) * pr);
+            iY = iY > 0 ? iY : 0;
+            const int iT = (int)(pt[k] / m.delta_heading);
+            in_table[k] = sane && !(iT < 0 || iT >= m.headings || iX >= pr || iY >= pr);
+            const uint32_t entry = in_table[k] ? (uint32_t)((iY * pr + iX) * m.headings + iT) : 0u;
+#pragma unroll
+            for (int wv = 0; wv < WORDS; ++wv)
+                win[k][wv] = in_table[k] ? s_win[entry * WORDS + wv] : 0u;
+            const int ox = (int)((win[k][(BB * BB) >> 5] >> ((BB * BB) & 31)) & 1u);
+            const int oy = (int)((win[k][(BB * BB + 1) >> 5] >> ((BB * BB + 1) & 31)) & 1u);
+            const int wx0 = X - (BB / 2 + ox), wy0 = Y - (BB / 2 + oy);
+            const int tx0 = wx0 >> 3, ty0 = wy0 >> 3;
+            sx[k] = wx0 & 7, sy[k] = wy0 & 7;
+            // which of the four tiles does the bitmap touch?
+            uint32_t low = 0, high = 0;
+#pragma unroll
+            for (int i = 0; i < BB; ++i)
+            {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int bit0 = i * BB, wv = bit0 >> 5, sh = bit0 & 31;
+                uint32_t rb = win[k][wv] >> sh;
+                if (sh + BB > 32 && wv + 1 < WORDS)
+                    rb |= win[k][wv + 1] << (32 - sh);
+                rb &= ROWMASK;
+                if (sy[k] + i < 8)
+                    low |= rb;
+                else
+                    high |= rb;
+            }
+            const uint32_t left_cols = (1u << (8 - sx[k])) - 1u; // box columns that fall into the left tile
+            const uint32_t need[4] = {low & left_cols, low & ~left_cols, high & left_cols, high & ~left_cols};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+            {
+                const int tx = tx0 + (t & 1), ty = ty0 + (t >> 1);
+                uint64_t v = 0;
+                if (need[t])
+                {
+                    v = ~0ull;
+                    if (tx >= 0 && (uint32_t)tx < m.tiles_x && ty >= 0 && (uint32_t)ty < m.tiles_y)
+                        v = m.occ_tiles[(size_t)ty * m.tiles_x + tx];
+                }
+                tile[k][t] = v;
+            }
+        }
+        // pass 2: rows of the box cut out of the tiles and tested against the bitmap
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            uint32_t hit = 0;
+#pragma unroll
+            for (int i = 0; i < BB; ++i)
+            {
+                const int bit0 = i * BB, wv = bit0 >> 5, sh = bit0 & 31;
+                uint32_t rb = win[k][wv] >> sh;
+                if (sh + BB > 32 && wv + 1 < WORDS)
+                    rb |= win[k][wv + 1] << (32 - sh);
+                rb &= ROWMASK;
+                const int r = sy[k] + i;
+                const bool upper = r >= 8;
+                const uint64_t L = upper ? tile[k][2] : tile[k][0], R = upper ? tile[k][3] : tile[k][1];
+                const int shr = 8 * (r & 7);
+                const uint32_t lb = (uint32_t)(L >> shr) & 0xffu, rbt = (uint32_t)(R >> shr) & 0xffu;
+                const uint32_t cells = ((lb | (rbt << 8)) >> sx[k]) & ROWMASK;
+                hit |= cells & rb;
+            }
+            v |= (in_table[k] && hit == 0) ? 1u << (8 * k) : 0u;
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(out + 4 * g));
+        a = na, b = nb, c = nc;
+        g = gn;
     }
     // the last n % 4 poses
     if (blockIdx.x == 0 && threadIdx.x < (n & 3))
@@ -1003,6 +1145,197 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
     }
 }
 
+// ---------------------------------------------------- 2D cost-to-goal flood
+// HybridAStar::BuildAStarCostMap (src/hybrid_a_star.cpp:1020-1074) with AStar::CreateSuccessor(pred, 8)
+// (src/a_star.cpp:214-277, step = resolution) and AStar::UpdateCostSoFar (:281-288): a lazy Dijkstra flood from the
+// goal over the whole grid (obstacles do not matter, only IsOnGrid).  Cell coordinates are floats accumulated along
+// the way the flood first reached the cell and a cell's cost is added up from float edge lengths, so the cost map
+// depends on the exact pop order of the reference's open queue; fl::push / fl::pop restate that queue.
+//
+// One query per wave (the algorithm is serial; the work is spread across queries).  Per cell the wave keeps
+// {cost, parent, state} in LDS; the open queue lives in LDS up to heap_cap entries and spills into `ws_heap` beyond;
+// cell coordinates go to `ws_xy` (read once per pop, for the parent, while the queue is being rearranged).  Every lane
+// runs the queue operations on the same values; lanes 0..7 look at one neighbour each.
+// Workgroup b handles queries b, b + gridDim.x, ... and owns slot b of the workspaces (n_cells entries each).
+typedef uint32_t flood_u32x4 __attribute__((ext_vector_type(4)));
+struct FloodHeap
+{
+    HYAS_LDS flood_u32x4 *lds;
+    flood_u32x4 *spill;
+    int cap;
+    __device__ __forceinline__ fl::Ent get(int i) const
+    {
+        flood_u32x4 v;
+        if (i < cap)
+            v = lds[i];
+        else
+            v = spill[i - cap];
+        fl::Ent e;
+        e.prio = __uint_as_float(v.x), e.id = v.y, e.x = __uint_as_float(v.z), e.y = __uint_as_float(v.w);
+        return e;
+    }
+    __device__ __forceinline__ void set(int i, const fl::Ent &e) const
+    {
+        const flood_u32x4 v = {__float_as_uint(e.prio), e.id, __float_as_uint(e.x), __float_as_uint(e.y)};
+        if (i < cap)
+            lds[i] = v;
+        else
+            spill[i - cap] = v;
+    }
+};
+
+// PS: {parent cell << 2 | state}; state 0 unseen, 1 open without parent (the goal), 2 open, 3 closed.
+template <typename PS, bool CELLS_IN_LDS>
+__global__ void __launch_bounds__(64) k_flood(DevMap m, const float *__restrict__ poses6, const uint32_t *__restrict__ qlist, uint32_t nq,
+                                              float *__restrict__ twod, float *__restrict__ start_cost, float2 *ws_xy, uint4 *ws_heap,
+                                              float *ws_g, PS *ws_ps, uint32_t heap_cap, uint32_t cells_pad)
+{
+    extern __shared__ uint4 s_flood[];
+    const int lane = threadIdx.x;
+    const uint32_t N = m.twod_size;
+    HYAS_LDS flood_u32x4 *s_heap = (HYAS_LDS flood_u32x4 *)s_flood;
+    HYAS_LDS float *s_g = (HYAS_LDS float *)(s_heap + heap_cap);
+    HYAS_LDS PS *s_ps = (HYAS_LDS PS *)(s_g + cells_pad);
+    float2 *xy = ws_xy + (size_t)blockIdx.x * N;
+    float *g_g = ws_g ? ws_g + (size_t)blockIdx.x * N : nullptr;
+    PS *g_ps = ws_ps ? ws_ps + (size_t)blockIdx.x * N : nullptr;
+    const FloodHeap heap{s_heap, (flood_u32x4 *)ws_heap + (size_t)blockIdx.x * N, (int)heap_cap};
+    auto ld_g = [&](uint32_t c) -> float { return CELLS_IN_LDS ? s_g[c] : g_g[c]; };
+    auto st_g = [&](uint32_t c, float v) {
+        if (CELLS_IN_LDS)
+            s_g[c] = v;
+        else
+            g_g[c] = v;
+    };
+    auto ld_ps = [&](uint32_t c) -> PS { return CELLS_IN_LDS ? s_ps[c] : g_ps[c]; };
+    auto st_ps = [&](uint32_t c, PS v) {
+        if (CELLS_IN_LDS)
+            s_ps[c] = v;
+        else
+            g_ps[c] = v;
+    };
+    for (uint32_t k = blockIdx.x; k < nq; k += gridDim.x)
+    {
+        const uint32_t q = qlist ? qlist[k] : k;
+        for (uint32_t c = lane; c < N; c += 64)
+            st_ps(c, (PS)0);
+        __syncthreads();
+        const float gx = poses6[6 * (size_t)q + 3], gy = poses6[6 * (size_t)q + 4];
+        const int gid = idx_2d(m, gx, gy);
+        int size = 0;
+        if (gid >= 0 && (uint32_t)gid < N) // src/hybrid_a_star.cpp:1026-1031: the goal opens the queue with cost 0
+        {
+            st_ps((uint32_t)gid, (PS)1);
+            st_g((uint32_t)gid, 0.f);
+            xy[gid] = make_float2(gx, gy);
+            fl::Ent e;
+            e.prio = 0.f, e.id = (uint32_t)gid, e.x = gx, e.y = gy;
+            heap.set(0, e);
+            size = 1;
+        }
+        const float step = m.res_f;
+        while (size > 0)
+        {
+            // ---- pop (every lane, same values) ----
+            const fl::Ent top = heap.get(0);
+            const uint32_t id = top.id;
+            const float cx = top.x, cy = top.y;
+            const PS p = ld_ps(id);
+            float cg = ld_g(id);
+            const bool has_parent = (p & 3) == 2;
+            float2 pxy = make_float2(0.f, 0.f);
+            if (has_parent)
+                pxy = xy[(uint32_t)(p >> 2)]; // in flight while the queue is rearranged
+            (void)fl::pop(heap, size);
+            --size;
+            if (has_parent) // AStar::UpdateCostSoFar: the edge from the parent is added when the cell is popped (:1041)
+                cg = cg + normf(sub(f2(cx, cy), f2(pxy.x, pxy.y)));
+            st_g(id, cg);
+            st_ps(id, (PS)(p | 3));
+            __syncthreads();
+            // ---- the eight neighbours, x offset outer, y offset inner (src/a_star.cpp:226-262) ----
+            bool act = false, want_push = false;
+            uint32_t nid = 0xffffffffu;
+            float xs = 0.f, ys = 0.f;
+            if (lane < 8)
+            {
+                const int o = lane + (lane >= 4 ? 1 : 0); // position in the 3 x 3 loop, centre left out
+                const int i = o / 3, j = o - 3 * i;
+                xs = cx + (i == 0 ? -step : i == 1 ? 0.f : step);
+                ys = cy + (j == 0 ? -step : j == 1 ? 0.f : step);
+                if (on_grid(m, xs, ys))
+                {
+                    const int n_ = idx_2d(m, xs, ys);
+                    if (n_ >= 0 && (uint32_t)n_ < N)
+                        nid = (uint32_t)n_, act = true;
+                }
+            }
+            // two neighbours in one cell (cannot happen on a regular grid, but nothing in the arithmetic forbids it):
+            // then the visits run one after the other, as the reference's loop does
+            bool clash = false;
+            for (int d = 1; d < 8; ++d)
+            {
+                const uint32_t other = (uint32_t)__shfl((int)nid, (lane + d) & 7, 64);
+                clash = clash || (act && other == nid);
+            }
+            const bool serial = __any(clash) != 0;
+            auto visit = [&]() {
+                const PS s = ld_ps(nid);
+                const int st = (int)(s & 3);
+                if (st == 3)
+                    return; // already popped: cost final (:1053)
+                if (st != 0)
+                {
+                    if (ld_g(nid) > cg) // :1056-1061: a cheaper parent; the queue keeps the old priority
+                        st_g(nid, cg), st_ps(nid, (PS)((id << 2) | 2u));
+                    return;
+                }
+                xy[nid] = make_float2(xs, ys);
+                st_g(nid, cg);
+                st_ps(nid, (PS)((id << 2) | 2u));
+                want_push = true;
+            };
+            if (!serial)
+            {
+                if (act)
+                    visit();
+            }
+            else
+                for (int l = 0; l < 8; ++l)
+                {
+                    if (lane == l && act)
+                        visit();
+                    __syncthreads();
+                }
+            __syncthreads();
+            // ---- pushes in loop order (:1066-1069) ----
+            unsigned long long mask = __ballot(want_push);
+            while (mask)
+            {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                fl::Ent e;
+                e.prio = cg;
+                e.id = (uint32_t)__shfl((int)nid, l, 64);
+                e.x = __shfl(xs, l, 64), e.y = __shfl(ys, l, 64);
+                fl::push(heap, size, e);
+                ++size;
+            }
+        }
+        __syncthreads();
+        // the cost map as BuildAStarCostMap leaves it: closed cells carry their cost, the rest are absent (-1)
+        float *out = twod + (size_t)q * N;
+        for (uint32_t c = lane; c < N; c += 64)
+            out[c] = ((ld_ps(c) & 3) == 3) ? ld_g(c) : -1.f;
+        if (start_cost && lane == 0)
+        {
+            const int sid = idx_2d(m, poses6[6 * (size_t)q], poses6[6 * (size_t)q + 1]);
+            start_cost[q] = (sid >= 0 && (uint32_t)sid < N && (ld_ps((uint32_t)sid) & 3) == 3) ? ld_g((uint32_t)sid) : -1.f;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------ launch wrappers
 static inline int grid_for(size_t n, int block = 256, int cap = 256 * 8)
 {
@@ -1016,7 +1349,32 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
 {
     if (n == 0)
         return;
-    if (mode == HYAS_MODE_FOOTPRINT && m.fp_pack && m.occ_tiles)
+    static const bool force_packed_lists = std::getenv("HYAS_FP_PACKED_LISTS") != nullptr; // the per-cell kernel, for comparison
+    if (mode == HYAS_MODE_FOOTPRINT && m.fp_win && m.occ_tiles && (m.fp_bb == 5 || m.fp_bb == 7 || m.fp_bb == 9) && !force_packed_lists)
+    {
+        // persistent grid: as many workgroups as fit on the chip, grid-stride over groups of four poses
+        const size_t lds = (size_t)m.fp_entries * m.fp_win_words * sizeof(uint32_t);
+        const int threads = m.fp_bb <= 5 ? 512 : 1024;
+        // workgroups resident per compute unit: the registers allow four waves per SIMD
+        const int per_cu = std::max(1, std::min<int>(1024 / threads, (int)((160 * 1024 - 512) / std::max<size_t>(lds, 1))));
+        const int blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)256 * per_cu, (n / 4 + threads - 1) / threads));
+        if (m.fp_bb == 5)
+        {
+            (void)hipFuncSetAttribute((const void *)k_collision_footprint_window<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_collision_footprint_window<5>, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
+        }
+        else if (m.fp_bb == 7)
+        {
+            (void)hipFuncSetAttribute((const void *)k_collision_footprint_window<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_collision_footprint_window<7>, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
+        }
+        else
+        {
+            (void)hipFuncSetAttribute((const void *)k_collision_footprint_window<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_collision_footprint_window<9>, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
+        }
+    }
+    else if (mode == HYAS_MODE_FOOTPRINT && m.fp_pack && m.occ_tiles)
     {
         // one workgroup per CU (the table takes most of its LDS), grid-stride over the poses
         const size_t lds = (size_t)m.fp_entries * sizeof(uint4);
@@ -1142,6 +1500,70 @@ void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hy
         hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_RS>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
     else
         hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_DUBINS>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
+}
+
+// Plans the launch of k_flood for maps of n_cells cells: how many workgroups (= workspace slots), how much LDS, and
+// which variant.  Cells live in LDS when {cost, parent | state} of every cell plus a queue of at least 256 entries fit;
+// the queue gets what is left of an equal share of the compute unit's LDS, so that several queries run per unit.
+FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override)
+{
+    FloodPlan fp{};
+    fp.n_cells = n_cells;
+    fp.narrow = n_cells <= 16384; // 14-bit parent + 2-bit state in 16 bits
+    const size_t ps = fp.narrow ? 2 : 4;
+    fp.cells_pad = (n_cells + 7u) & ~7u;
+    const size_t cell_bytes = (size_t)fp.cells_pad * (4 + ps);
+    const size_t lds_total = 160 * 1024, margin = 1024;
+    fp.cells_in_lds = false;
+    int per_cu = 1;
+    size_t heap_cap = 1024;
+    for (int k : {8, 4, 2, 1})
+    {
+        const size_t budget = lds_total / k - margin;
+        if (cell_bytes + 256 * 16 <= budget)
+        {
+            fp.cells_in_lds = true, per_cu = k;
+            heap_cap = std::min<size_t>(1024, (budget - cell_bytes) / 16);
+            break;
+        }
+    }
+    if (!fp.cells_in_lds)
+        per_cu = 8, heap_cap = 1024;
+    heap_cap = std::min<size_t>(heap_cap, std::max<uint32_t>(n_cells, 1));
+    if (heap_cap_override > 0)
+        heap_cap = (size_t)heap_cap_override;
+    fp.heap_cap = (uint32_t)heap_cap;
+    fp.lds_bytes = heap_cap * 16 + (fp.cells_in_lds ? cell_bytes : 0);
+    fp.grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_queries, (size_t)256 * per_cu));
+    fp.ws_xy_bytes = (size_t)fp.grid * n_cells * sizeof(float2);
+    fp.ws_heap_bytes = (size_t)fp.grid * n_cells * sizeof(uint4);
+    fp.ws_g_bytes = fp.cells_in_lds ? 0 : (size_t)fp.grid * n_cells * sizeof(float);
+    fp.ws_ps_bytes = fp.cells_in_lds ? 0 : (size_t)fp.grid * n_cells * ps;
+    return fp;
+}
+
+template <typename PS, bool L>
+static hipError_t launch_flood_as(const DevMap &m, const FloodPlan &fp, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod,
+                                  float *start_cost, void *ws_xy, void *ws_heap, void *ws_g, void *ws_ps, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_flood<PS, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL((k_flood<PS, L>), dim3(fp.grid), dim3(64), fp.lds_bytes, s, m, poses6, qlist, nq, twod, start_cost, (float2 *)ws_xy,
+                       (uint4 *)ws_heap, (float *)ws_g, (PS *)ws_ps, fp.heap_cap, fp.cells_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_flood(const DevMap &m, const FloodPlan &fp, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod,
+                        float *start_cost, void *ws_xy, void *ws_heap, void *ws_g, void *ws_ps, hipStream_t s)
+{
+    if (!nq)
+        return hipSuccess;
+    if (fp.narrow)
+        return fp.cells_in_lds ? launch_flood_as<uint16_t, true>(m, fp, poses6, qlist, nq, twod, start_cost, ws_xy, ws_heap, ws_g, ws_ps, s)
+                               : launch_flood_as<uint16_t, false>(m, fp, poses6, qlist, nq, twod, start_cost, ws_xy, ws_heap, ws_g, ws_ps, s);
+    return fp.cells_in_lds ? launch_flood_as<uint32_t, true>(m, fp, poses6, qlist, nq, twod, start_cost, ws_xy, ws_heap, ws_g, ws_ps, s)
+                           : launch_flood_as<uint32_t, false>(m, fp, poses6, qlist, nq, twod, start_cost, ws_xy, ws_heap, ws_g, ws_ps, s);
 }
 
 } // namespace hyas

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -562,6 +563,35 @@ int host_threads()
 
 } // namespace
 
+// Worker threads of the search driver, kept in the context between calls: one pool for the set-up and finishing
+// steps of a chunk, and one per driver thread for the rounds.  Idle workers block after a short spin.
+struct SearchPools
+{
+    std::unique_ptr<Pool> main;
+    std::vector<std::unique_ptr<Pool>> driver;
+    int driver_threads = 0;
+    Pool &main_pool(int threads)
+    {
+        if (!main || main->size() != std::max(1, threads))
+            main.reset(new Pool(threads));
+        return *main;
+    }
+    // n pools of `threads` threads each
+    void driver_pools(int n, int threads)
+    {
+        if (driver_threads != threads)
+            driver.clear(), driver_threads = threads;
+        while ((int)driver.size() < n)
+            driver.emplace_back(new Pool(threads));
+    }
+};
+
+void free_search_pools(hyas_ctx *c)
+{
+    delete c->pools;
+    c->pools = nullptr;
+}
+
 // queries per group
 static size_t gcap_hint(size_t cn, int ng) { return (cn + ng - 1) / ng; }
 
@@ -576,11 +606,22 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     c->expanded.assign(n, std::vector<int32_t>());
     if (n == 0)
         return HYAS_OK;
-    Pool pool(host_threads());
+    if (!c->pools)
+        c->pools = new SearchPools();
+    Pool &pool = c->pools->main_pool(host_threads());
 
-    // Queries are processed in chunks so the per-query 2D cost maps of one
-    // chunk fit a fixed device buffer.
+    // Queries are processed in chunks: each query of a chunk owns a 2D cost map in device memory, so a chunk takes
+    // at most a quarter of the free device memory (8192 queries at most; HYAS_CHUNK overrides).
+    const size_t twod = c->twod_size;
     size_t chunk_cap = 8192;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+            (void)hipGetLastError(), free_b = (size_t)8 << 30;
+        const size_t per_query = twod * sizeof(float) + 4096;
+        const size_t reuse = c->d_twod_bytes; // already held by this context
+        chunk_cap = std::min<size_t>(chunk_cap, std::max<size_t>(16, (free_b / 4 + reuse) / per_query));
+    }
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
     // Query groups in flight at once, two per driver thread, so that a driver does the host part of one group while
@@ -601,8 +642,19 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     int spec_cfg = 6;
     if (const char *e = std::getenv("HYAS_SPEC"))
         spec_cfg = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
-    const size_t twod = c->twod_size;
+    int drivers_cfg = 0;
+    if (const char *e = std::getenv("HYAS_DRIVERS"))
+        drivers_cfg = std::max(1, std::atoi(e));
+    const bool trace_on = std::getenv("HYAS_TRACE") != nullptr;
     std::vector<float> shot_buf;
+    // a failed HIP call may leave kernels of other groups in flight that write into the staging block: wait for them
+    auto drain = [&](int rc) {
+        for (int g = 0; g < HYAS_MAX_GROUPS; ++g)
+            if (c->round_stream[g])
+                (void)hipStreamSynchronize(c->round_stream[g]);
+        (void)hipGetLastError();
+        return rc;
+    };
 
     for (size_t base = 0; base < n; base += chunk_cap)
     {
@@ -622,16 +674,16 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         const int spec_k = spec_cfg;
         const size_t KS = (size_t)spec_k;
         const size_t o_in = take(cn * KS * sizeof(StepIn));
-        int max_drivers = std::max(1, ng / 2);
-        if (const char *e = std::getenv("HYAS_DRIVERS"))
-            max_drivers = std::max(1, std::atoi(e));
+        const int max_drivers = drivers_cfg ? drivers_cfg : std::max(1, ng / 2);
         const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
         const int threads_per_driver =
             (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
         const size_t o_succ = take(ng * res_stride(gcap * KS));
         const size_t o_goal = take(cn * sizeof(hyas_goal));
-        const size_t o_twod_host = take(cn * twod * sizeof(float));
-        int rc = ensure_scratch(c, o_twod_host, off);
+        // set-up staging: poses {start, goal}, relative poses for the table lookup, their results
+        const size_t o_poses = take(cn * 6 * sizeof(float)), o_rel = take(cn * 3 * sizeof(float)), o_cost = take(cn * sizeof(float)),
+                     o_ok = take(cn * 2 + 4), o_qlist = take(cn * sizeof(uint32_t)), o_startc = take(cn * sizeof(float));
+        int rc = ensure_scratch(c, off, off);
         if (rc != HYAS_OK)
             return rc;
         if ((rc = ensure_twod(c, cn * twod * sizeof(float))) != HYAS_OK)
@@ -639,85 +691,81 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         char *hs = (char *)c->h_scratch, *ds = (char *)c->d_scratch;
         StepIn *h_in = (StepIn *)(hs + o_in);
         hyas_goal *h_goal = (hyas_goal *)(hs + o_goal);
-        float *h_twod = (float *)(hs + o_twod_host);
 
-        // makePlan pre-checks (src/hybrid_a_star_planner.cpp:126-155): start
-        // and goal poses through the pose test on the GPU
-        std::vector<float> poses(cn * 6);
+        // makePlan pre-checks (src/hybrid_a_star_planner.cpp:126-155): start and goal poses through the pose test;
+        // the start node's curve cost (:63) from the heuristic table: both on the GPU, in one trip
+        float *poses = (float *)(hs + o_poses), *rel = (float *)(hs + o_rel), *cost = (float *)(hs + o_cost),
+              *start_cost = (float *)(hs + o_startc);
+        uint8_t *pose_ok = (uint8_t *)(hs + o_ok);
+        uint32_t *qlist = (uint32_t *)(hs + o_qlist);
         for (size_t i = 0; i < cn; ++i)
         {
             const float *s = starts + 3 * (base + i), *g = goals + 3 * (base + i);
             // Utility::TypeConversion(PoseStamped -> Node3D), src/utility.cpp:7-13
-            poses[6 * i] = s[0], poses[6 * i + 1] = s[1], poses[6 * i + 2] = rad_0_2pi(s[2]);
-            poses[6 * i + 3] = g[0], poses[6 * i + 4] = g[1], poses[6 * i + 5] = rad_0_2pi(g[2]);
+            float *p = poses + 6 * i;
+            p[0] = s[0], p[1] = s[1], p[2] = rad_0_2pi(s[2]);
+            p[3] = g[0], p[4] = g[1], p[5] = rad_0_2pi(g[2]);
+            h_goal[i] = hyas_goal{p[3], p[4], p[5]};
+            rel[3 * i] = hy_fabsf(p[3] - p[0]), rel[3 * i + 1] = hy_fabsf(p[4] - p[1]), rel[3 * i + 2] = p[5] - p[2];
         }
-        std::vector<uint8_t> pose_ok(cn * 2);
-        rc = hyas_collision_batch(c, HYAS_MODE_POLYGON, poses.data(), nullptr, cn * 2, pose_ok.data());
-        if (rc != HYAS_OK)
-            return rc;
-
-        // per-query set-up: 2D cost map, start node
-        pool.run(cn, [&](size_t a, size_t b) {
-            for (size_t i = a; i < b; ++i)
+        HYAS_HIP(c, hipMemcpyAsync(ds + o_goal, hs + o_goal, o_cost - o_goal, hipMemcpyHostToDevice, c->stream)); // goals, poses, rel
+        launch_collision(m, HYAS_MODE_POLYGON, (const float *)(ds + o_poses), nullptr, cn * 2, (uint8_t *)(ds + o_ok), c->stream);
+        launch_table_lookup(m, (const float *)(ds + o_rel), cn, (float *)(ds + o_cost), c->stream);
+        HYAS_HIP(c, hipGetLastError());
+        HYAS_HIP(c, hipMemcpyAsync(hs + o_cost, ds + o_cost, o_qlist - o_cost, hipMemcpyDeviceToHost, c->stream)); // costs, verdicts
+        HYAS_HIP(c, hipStreamSynchronize(c->stream));
+        size_t n_flood = 0;
+        for (size_t i = 0; i < cn; ++i)
+        {
+            Query &q = Q[i];
+            const float *p = poses + 6 * i;
+            q.goal = h_goal[i];
+            q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1}; // Node3D(): g = 999, prim = 0
+            uint32_t gx, gy;
+            bool bad = !pose_ok[2 * i];
+            if (!world_to_map(m, p[3], p[4], gx, gy))
+                bad = true;
+            else if (pose_ok[2 * i + 1] && c->charmap[gx + gy * m.w] > 252)
+                bad = true;
+            if (bad)
             {
+                q.res.status = HYAS_STATUS_BAD_POSE;
+                q.done = true;
+                continue;
+            }
+            qlist[n_flood++] = (uint32_t)i;
+        }
+        // 2D cost map of every goal (src/hybrid_a_star.cpp:59), on the GPU, straight into the buffer the round kernel
+        // reads; the host only needs the cost at each start cell
+        if (n_flood)
+        {
+            HYAS_HIP(c, hipMemcpyAsync(ds + o_qlist, qlist, n_flood * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            if ((rc = flood_dev(c, (const float *)(ds + o_poses), (const uint32_t *)(ds + o_qlist), (uint32_t)n_flood, c->d_twod,
+                                (float *)(ds + o_startc), c->stream)) != HYAS_OK)
+                return rc;
+            HYAS_HIP(c, hipMemcpyAsync(start_cost, ds + o_startc, cn * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HYAS_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        const double wall_flood = since(wall0);
+        // per-query set-up: search structures and the start node (:61-78)
+        pool.run(n_flood, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; ++k)
+            {
+                const size_t i = qlist[k];
                 Query &q = Q[i];
-                const float *p = &poses[6 * i];
-                q.goal = hyas_goal{p[3], p[4], p[5]};
-                h_goal[i] = q.goal;
-                q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1}; // Node3D(): g = 999, prim = 0
-                uint32_t gx, gy;
-                bool bad = !pose_ok[2 * i];
-                if (!world_to_map(m, p[3], p[4], gx, gy))
-                    bad = true;
-                else if (pose_ok[2 * i + 1] && c->charmap[gx + gy * m.w] > 252)
-                    bad = true;
-                if (bad)
-                {
-                    q.res.status = HYAS_STATUS_BAD_POSE;
-                    q.done = true;
-                    std::fill(h_twod + i * twod, h_twod + (i + 1) * twod, -1.f);
-                    continue;
-                }
-                flood_2d(c, q.goal.x, q.goal.y, h_twod + i * twod);
                 q.cells.init(1024);
                 q.dup_head.assign(1 << 11, -1);
                 q.arena.reserve(1024);
-            }
-        });
-        // the start node's heuristic (:63) comes from the same table / 2D map the
-        // kernels use: evaluate it on the host copy of the 2D map + a table lookup
-        {
-            std::vector<float> rel(cn * 3), cost(cn);
-            for (size_t i = 0; i < cn; ++i)
-            {
-                const Query &q = Q[i];
-                rel[3 * i] = hy_fabsf(q.goal.x - q.start.x), rel[3 * i + 1] = hy_fabsf(q.goal.y - q.start.y);
-                rel[3 * i + 2] = q.goal.t - q.start.t;
-            }
-            rc = hyas_table_lookup(c, rel.data(), cn, cost.data());
-            if (rc != HYAS_OK)
-                return rc;
-            for (size_t i = 0; i < cn; ++i)
-            {
-                Query &q = Q[i];
-                if (q.done)
-                    continue;
-                float two_d = 0;
-                int id = idx_2d(m, q.start.x, q.start.y);
-                if (id >= 0 && (size_t)id < twod && h_twod[i * twod + id] >= 0)
-                    two_d = h_twod[i * twod + id];
+                const float two_d = start_cost[i] >= 0 ? start_cost[i] : 0.f;
                 q.start.h = fmaxf_(cost[i], two_d);
                 q.N = (int)q.start.h;
-                D.push(q, q.start, idx_3d(c->dm, q.start.x, q.start.y, q.start.t));
-                CellMap::Slot &cell = q.cells.get(idx_3d(m, q.start.x, q.start.y, q.start.t));
+                const int idx = idx_3d(m, q.start.x, q.start.y, q.start.t);
+                D.push(q, q.start, idx);
+                CellMap::Slot &cell = q.cells.get(idx);
                 cell.g = q.start.g, cell.open = 1, cell.closed = 0;
             }
-        }
+        });
 
-        // the calls above reuse the device scratch: size it for the rounds now
-        if ((rc = ensure_scratch(c, o_twod_host, off)) != HYAS_OK)
-            return rc;
-        ds = (char *)c->d_scratch;
         char *hd = nullptr; // the pinned host block as the GPU addresses it
         HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
         // the popped nodes go into device memory the host can store into, where there is such memory, else into the
@@ -726,10 +774,6 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             return rc;
         StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
         const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
-        HYAS_HIP(c, hipMemcpyAsync(c->d_twod, h_twod, cn * twod * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HYAS_HIP(c, hipMemcpyAsync(ds + o_goal, h_goal, cn * sizeof(hyas_goal), hipMemcpyHostToDevice, c->stream));
-        HYAS_HIP(c, hipStreamSynchronize(c->stream));
-
 
         // rounds.  The chunk's queries form groups that advance independently: every group has its own stream and
         // slice of the staging block; up to four driver threads (with helper threads) each look after a share of
@@ -906,7 +950,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 G[d].rc = HYAS_ENODEV;
                 return;
             }
-            Pool gp(threads_per_driver);
+            Pool &gp = *c->pools->driver[d];
             bool inflight[HYAS_MAX_GROUPS] = {false};
             for (int gi = d; gi < ng; gi += n_drivers)
                 if (host_round(G[gi], gp, false))
@@ -932,6 +976,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             }
         };
         const double wall_setup = since(wall0);
+        c->pools->driver_pools(n_drivers, threads_per_driver);
         {
             std::vector<std::thread> drivers;
             for (int d = 1; d < n_drivers; ++d)
@@ -945,17 +990,17 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         for (int gi = 0; gi < ng; ++gi)
         {
             if (G[gi].rc != HYAS_OK)
-                return c->fail(G[gi].rc, "a HIP call failed in a search round");
+                return drain(c->fail(G[gi].rc, "a HIP call failed in a search round"));
             c->k_ms[0] += G[gi].k_ms, c->k_launches[0] += G[gi].launches;
             t_host = std::max(t_host, G[gi].t_host), t_launch = std::max(t_launch, G[gi].t_launch), t_wait = std::max(t_wait, G[gi].t_wait);
         }
 
-        if (std::getenv("HYAS_TRACE"))
+        if (trace_on)
             fprintf(stderr,
                     "hyas rounds (%d groups, %d drivers x %d threads, %d nodes per query; slowest group): host push+pop %.3f s, launch %.3f s, "
-                    "wait %.3f s; %llu expansions answered ahead of time; wall: set-up %.3f s, rounds %.3f s\n",
+                    "wait %.3f s; %llu expansions answered ahead of time; wall: set-up %.3f s (pose checks + 2D floods %.3f s), rounds %.3f s\n",
                     ng, n_drivers, threads_per_driver, spec_k, t_host, t_launch, t_wait, (unsigned long long)spec_hits.load(), wall_setup,
-                    wall_rounds);
+                    wall_flood, wall_rounds);
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
@@ -983,8 +1028,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 size_t total = 0;
                 for (size_t k = 0; k < nsq; ++k)
                     h_off[k] = (uint32_t)total, total += h_cnt[k];
-                float *d_pts = nullptr;
-                HYAS_HIP(c, hipMalloc((void **)&d_pts, std::max<size_t>(total, 1) * 3 * sizeof(float)));
+                if ((rc = ensure_buffer(c, (void **)&c->d_pts, &c->d_pts_bytes, std::max<size_t>(total, 1) * 3 * sizeof(float))) != HYAS_OK)
+                    return rc;
+                float *d_pts = c->d_pts;
                 shot_buf.resize(total * 3);
                 hipError_t e = hipMemcpyAsync(d_off, h_off, nsq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
                 if (e == hipSuccess)
@@ -997,7 +1043,6 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     e = hipMemcpyAsync(shot_buf.data(), d_pts, total * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess)
                     e = hipStreamSynchronize(c->stream);
-                (void)hipFree(d_pts);
                 if (e != hipSuccess)
                     return hip_fail(c, e, "shot path download");
                 pool.run(nsq, [&](size_t a, size_t b) {
@@ -1019,7 +1064,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             c->paths[base + i].swap(Q[i].path);
             c->expanded[base + i].swap(Q[i].expanded);
         }
-        if (std::getenv("HYAS_TRACE"))
+        if (trace_on)
             fprintf(stderr, "hyas chunk of %zu queries: %.3f s in all, %.3f s after the rounds\n", cn, since(wall0),
                     since(wall0) - wall_setup - wall_rounds);
     }

@@ -6,6 +6,36 @@ xGMI on the GPU box, "gloo" in the CPU tests)."""
 import numpy as np
 
 
+def load_map(name):
+    """One of the occupancy maps the benchmarks and tests run on (uint8 [h][w], costmap_2d cost values), converted
+    from the reference's maps/*.png by tests/golden/make_maps.py."""
+    from pathlib import Path
+
+    return np.load(Path(__file__).resolve().parent.parent / "tests" / "golden" / "maps" / f"{name}.npy")
+
+
+def launch_ranks(script, argv, n, timeout=None):
+    """Starts `n` processes of `script argv...`, one per GPU, with the torch.distributed environment
+    (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR, MASTER_PORT) set, before this process has touched a
+    GPU.  Returns (exit codes, rank 0's stdout).  Ranks other than 0 inherit stdout / stderr."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, str(script)] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
+    out0, _ = procs[0].communicate(timeout=timeout)
+    codes = [procs[0].returncode] + [p.wait(timeout=timeout) for p in procs[1:]]
+    return codes, out0
+
+
 def query_shard(n_total, rank, world):
     """Contiguous block [begin, end) of n_total queries for `rank`; blocks differ by at most one query."""
     base, extra = divmod(n_total, world)

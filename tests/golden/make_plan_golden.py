@@ -56,6 +56,10 @@ def main():
     o = orc.Oracle(orc.hot_path_params(position_resolution=2))
     o.set_costmap(orc.load_map("map_parking"), build_table=True, nthreads=8)
     record("parking_fixed", o, "map_parking", 2, (2, 28, 0), (58, 2, 0))
+    # the same query with the parameters the single-query configuration is quoted on (position_resolution 10)
+    o = orc.Oracle(orc.hot_path_params())
+    o.set_costmap(orc.load_map("map_parking"), build_table=True, nthreads=8)
+    record("parking_fixed_pr10", o, "map_parking", 10, (2, 28, 0), (58, 2, 0))
     o = orc.Oracle(orc.hot_path_params(position_resolution=2))
     o.set_costmap(orc.load_map("map_maze"), build_table=True, nthreads=8)
     S, G = maze_queries(o)

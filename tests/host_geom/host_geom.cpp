@@ -9,6 +9,8 @@
 #include "../../path_planner_amd/csrc/hyas_dev.h"
 #include "../../path_planner_amd/csrc/hyas_prune.h"
 #include "../../path_planner_amd/csrc/hyas_rs.h"
+#include "../../path_planner_amd/csrc/hyas_flood.h"
+#include <queue>
 
 using namespace hyas;
 
@@ -149,4 +151,130 @@ extern "C" long hg_rs_interp_mismatches(const double *xyphi, int n, int per, dou
         }
     }
     return bad;
+}
+
+// The flood kernel's open queue (fl::push / fl::pop over flat storage) against std::priority_queue with the
+// reference's `>=` comparator (include/hybrid_a_star.h:45-53): a random mix of pushes and pops with many equal
+// priorities; returns the number of pops whose cell differs.
+struct VecHeap
+{
+    std::vector<fl::Ent> v;
+    fl::Ent get(int i) const { return v[(size_t)i]; }
+    void set(int i, const fl::Ent &e)
+    {
+        if ((size_t)i >= v.size())
+            v.resize((size_t)i + 1);
+        v[(size_t)i] = e;
+    }
+};
+struct RefCmp
+{
+    bool operator()(const std::pair<int, double> &l, const std::pair<int, double> &r) const { return l.second >= r.second; }
+};
+extern "C" long hg_heap_mismatches(const float *prio, const uint8_t *is_pop, int n_ops)
+{
+    VecHeap h;
+    int size = 0;
+    std::priority_queue<std::pair<int, double>, std::vector<std::pair<int, double>>, RefCmp> pq;
+    long bad = 0;
+    for (int i = 0; i < n_ops; i++)
+    {
+        if (is_pop[i])
+        {
+            if (pq.empty())
+                continue;
+            const int want = pq.top().first;
+            pq.pop();
+            const fl::Ent got = fl::pop(h, size);
+            --size;
+            bad += (int)got.id != want;
+        }
+        else
+        {
+            fl::Ent e;
+            e.prio = prio[i], e.id = (uint32_t)i, e.x = 0, e.y = 0;
+            fl::push(h, size, e);
+            ++size;
+            pq.emplace(i, (double)prio[i]);
+        }
+    }
+    while (!pq.empty())
+    {
+        const int want = pq.top().first;
+        pq.pop();
+        const fl::Ent got = fl::pop(h, size);
+        --size;
+        bad += (int)got.id != want;
+    }
+    return bad;
+}
+
+// The flood kernel's algorithm run serially on the host: per cell {cost, parent, state}, coordinates kept apart,
+// the edge from the parent added at pop time from the stored coordinates of both cells.
+// out: w*h + w + 1 floats, -1 where the flood never closed the cell.
+extern "C" void hg_flood(int w, int h, double res, double ox, double oy, float gx, float gy, float *out)
+{
+    DevMap m{};
+    m.w = w, m.h = h, m.res = res, m.ox = ox, m.oy = oy, m.res_f = (float)res, m.ox_f = (float)ox, m.oy_f = (float)oy;
+    int e = 0;
+    const bool p2 = std::frexp(res, &e) == 0.5 && (double)m.res_f == res;
+    m.res_pow2 = p2, m.inv_res = p2 ? 1.0 / res : 0, m.inv_res_f = p2 ? (float)(1.0 / res) : 0;
+    const uint32_t N = (uint32_t)w * h + w + 1;
+    m.twod_size = N;
+    std::vector<float> g(N, 0.f), X(N, 0.f), Y(N, 0.f);
+    std::vector<uint32_t> ps(N, 0);
+    VecHeap heap;
+    int size = 0;
+    const int gid = idx_2d(m, gx, gy);
+    if (gid >= 0 && (uint32_t)gid < N)
+    {
+        ps[gid] = 1, g[gid] = 0, X[gid] = gx, Y[gid] = gy;
+        fl::Ent en;
+        en.prio = 0, en.id = (uint32_t)gid, en.x = gx, en.y = gy;
+        heap.set(0, en);
+        size = 1;
+    }
+    const float step = m.res_f;
+    while (size > 0)
+    {
+        const fl::Ent top = fl::pop(heap, size);
+        --size;
+        const uint32_t id = top.id;
+        const float cx = top.x, cy = top.y;
+        float cg = g[id];
+        if ((ps[id] & 3) == 2)
+        {
+            const uint32_t par = ps[id] >> 2;
+            cg = cg + normf(sub(f2(cx, cy), f2(X[par], Y[par])));
+        }
+        g[id] = cg, ps[id] |= 3;
+        for (int o = 0; o < 9; o++)
+        {
+            if (o == 4)
+                continue;
+            const int i = o / 3, j = o % 3;
+            const float xs = cx + (i == 0 ? -step : i == 1 ? 0.f : step), ys = cy + (j == 0 ? -step : j == 1 ? 0.f : step);
+            if (!on_grid(m, xs, ys))
+                continue;
+            const int n_ = idx_2d(m, xs, ys);
+            if (n_ < 0 || (uint32_t)n_ >= N)
+                continue;
+            const int st = ps[n_] & 3;
+            if (st == 3)
+                continue;
+            if (st != 0)
+            {
+                if (g[n_] > cg)
+                    g[n_] = cg, ps[n_] = (id << 2) | 2u;
+                continue;
+            }
+            X[n_] = xs, Y[n_] = ys, g[n_] = cg, ps[n_] = (id << 2) | 2u;
+            fl::Ent en;
+            en.prio = cg, en.id = (uint32_t)n_, en.x = xs, en.y = ys;
+            fl::push(heap, size, en);
+            ++size;
+        }
+    }
+    for (uint32_t c = 0; c < N; c++)
+        out[c] = (ps[c] & 3) == 3 ? g[c] : -1.f;
 }

@@ -122,7 +122,7 @@ class Oracle:
                   "orc_table_lookup", "orc_plan", "orc_get_path", "orc_get_expanded", "orc_footprint_table",
                   "orc_get_obstacles", "orc_in_range_count", "orc_num_obstacles", "orc_num_successors",
                   "orc_table_dims", "orc_build_table", "orc_rs_path", "orc_rs_sample", "orc_dubins",
-                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid"):
+                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid", "orc_plan_r"):
             getattr(L, f).argtypes = None
         self.params = params
         self.h = C.c_void_p(L.orc_create(C.byref(params)))
@@ -244,6 +244,20 @@ class Oracle:
         exp = np.zeros(max(1, int(res["nodes_expanded"][0])), np.int32)
         m = self.L.orc_get_expanded(self.h, exp.ctypes.data_as(C.c_void_p), C.c_size_t(exp.shape[0]))
         return res[0], path[:n].copy(), exp[:m].copy()
+
+    def plan_r(self, start, goal, path_cap=40000, exp_cap=12000):
+        """plan() with caller-owned outputs: safe to call from several threads on one context."""
+        s = np.asarray(start, np.float32)
+        g = np.asarray(goal, np.float32)
+        res = np.zeros(1, RESULT_DT)
+        path = np.zeros((path_cap, 3), np.float32)
+        exp = np.zeros(exp_cap, np.int32)
+        pn, en = C.c_int32(), C.c_int32()
+        self.L.orc_plan_r(self.h, s.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p),
+                          path.ctypes.data_as(C.c_void_p), C.c_size_t(path_cap), C.byref(pn), exp.ctypes.data_as(C.c_void_p),
+                          C.c_size_t(exp_cap), C.byref(en))
+        assert pn.value <= path_cap and en.value <= exp_cap
+        return res[0], path[:pn.value].copy(), exp[:en.value].copy()
 
     def plan_many(self, starts, goals):
         starts = np.ascontiguousarray(starts, np.float32)

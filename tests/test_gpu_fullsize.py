@@ -152,17 +152,26 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
     h = maze_ctx
     S, G = make_queries(h.collision, 300, 77, 50, 50)
     base = h.plan_batch(S, G)
+    default_path = h.nodes_in_device_memory()
     keep = [(h.path(i), h.expanded(i)) for i in range(300)]
     assert base["nodes_expanded"].sum() > 100000
     for env in (dict(HYAS_SPEC="1", HYAS_GROUPS="1", HYAS_THREADS="1"), dict(HYAS_SPEC="2", HYAS_GROUPS="3", HYAS_THREADS="5"),
                 dict(HYAS_SPEC="8", HYAS_GROUPS="8", HYAS_THREADS="16"), dict(HYAS_SPEC="4", HYAS_CHUNK="97"),
                 dict(HYAS_SPEC="8", HYAS_SPEC_ADAPT="0", HYAS_GROUPS="16", HYAS_DRIVERS="2"),
-                dict(HYAS_SPEC="5", HYAS_SPEC_FLOOR="0", HYAS_DRIVERS="8")):
-        for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS"):
+                dict(HYAS_SPEC="5", HYAS_SPEC_FLOOR="0", HYAS_DRIVERS="8"),
+                dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"), dict()):
+        for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS",
+                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         res = h.plan_batch(S, G)
+        # which way the popped nodes travelled: pinned host memory when asked for; otherwise device memory wherever
+        # the GPU offers a host mapping (the last, empty case runs after the switch and must be back on that path)
+        if "HYAS_NODES_IN_HOST_MEMORY" in env:
+            assert not h.nodes_in_device_memory()
+        elif env == {}:
+            assert h.nodes_in_device_memory() == default_path
         assert res.tobytes() == base.tobytes(), env
         for i in range(0, 300, 7):
             assert np.array_equal(h.path(i), keep[i][0]) and np.array_equal(h.expanded(i), keep[i][1]), (env, i)

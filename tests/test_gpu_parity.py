@@ -130,12 +130,37 @@ def test_table(parking):
         assert np.array_equal(p.o.table_lookup(g).view(np.uint32), p.h.table_lookup(g).view(np.uint32))
 
 
-def test_flood(parking, maze):
-    for p, seed in ((parking, 31), (maze, 32)):
-        for g in p.free_poses(4, seed):
-            a, b = p.o.flood(g), p.h.flood(g)
+def test_flood(parking, maze, monkeypatch):
+    """2D cost-to-goal flood (src/hybrid_a_star.cpp:1020-1074) from the GPU kernel against the oracle: goals anywhere
+    on the map incl. its corners; with the kernel's open queue held in LDS and with almost all of it pushed out into
+    the spill area."""
+    for heap in (None, "8"):
+        if heap:
+            monkeypatch.setenv("HYAS_FLOOD_HEAP", heap)
+        for p, seed in ((parking, 31), (maze, 32)):
+            goals = list(p.free_poses(5, seed)) + [np.array([0.01, 0.01, 0], np.float32),
+                                                   np.array([p.W - 0.01, p.H - 0.01, 1], np.float32),
+                                                   np.array([p.W * 0.5, 0.0, 2], np.float32)]
+            for g in goals[: (3 if heap else len(goals))]:
+                a, b = p.o.flood(g), p.h.flood(g)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+                assert (a >= 0).sum() >= p.W * p.H - 1
+            # a goal off the map floods nothing
+            a, b = p.o.flood((-5.0, 3.0, 0.0)), p.h.flood((-5.0, 3.0, 0.0))
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-            assert (a >= 0).sum() >= p.W * p.H - 1
+        monkeypatch.delenv("HYAS_FLOOD_HEAP", raising=False)
+
+
+def test_flood_large_and_shifted_maps(oracle_built):
+    """The flood on the largest in-tree map (two queries per compute unit's LDS) and on a map with 0.5 m cells and a
+    shifted origin (cell coordinates that are not whole numbers)."""
+    for name, res, ox, oy in (("map_large", 1.0, 0.0, 0.0), ("map_basic", 0.5, -3.25, 2.5)):
+        p = Pair(name, res=res, ox=ox, oy=oy, position_resolution=1)
+        rng = np.random.default_rng(5)
+        for _ in range(4):
+            g = (ox + rng.uniform(0, p.W * res), oy + rng.uniform(0, p.H * res), 0.0)
+            a, b = p.o.flood(g), p.h.flood(g)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, g)
 
 
 def _nodes(p, n, seed):
@@ -377,6 +402,21 @@ def test_abi_error_behaviour():
     g.set_grid(np.zeros((16, 16), np.uint8))
     assert L.hyas_collision_batch(g.h, 0, vp(buf), None, 4, vp(out)) == hl.ESTATE
     assert L.hyas_collision_batch(g.h, 1, vp(buf), None, 4, vp(out)) == hl.OK
+    # a context that had a costmap and then got a bare grid: nothing of the costmap is left to read or launch on
+    g2 = Hyas(hl.hot_path_params(position_resolution=1))
+    g2.set_costmap(orc.load_map("map_small"), build_table=True)
+    assert g2.in_range_count(0) >= 0
+    g2.set_grid(np.zeros((16, 16), np.uint8))
+    a, b, c_ = C.c_int32(), C.c_int32(), C.c_int32()
+    assert L.hyas_table_dims(g2.h, C.byref(a), C.byref(b), C.byref(c_)) == hl.ESTATE
+    assert L.hyas_table_build_dev(g2.h, 1, 0, 1, vp(buf)) == hl.ESTATE
+    assert L.hyas_table_install_dev(g2.h, 1, vp(buf)) == hl.ESTATE
+    assert L.hyas_in_range_count(g2.h, 0) == -1
+    assert L.hyas_get_obstacles(g2.h, None, 0) == hl.ESTATE
+    assert L.hyas_flood(g2.h, vp(buf), vp(buf)) == hl.ESTATE
+    assert L.hyas_collision_batch(g2.h, 1, vp(buf), None, 4, vp(out)) == hl.OK
+    # install with an unknown curve type
+    assert L.hyas_table_install_dev(h.h, 5, vp(buf)) == hl.EINVAL
     # an empty plan batch is fine once everything is set up
     h.set_costmap(orc.load_map("map_small"), build_table=True)
     res = h.plan_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))

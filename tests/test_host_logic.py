@@ -23,7 +23,7 @@ HG = ROOT / "tests" / "host_geom"
 def host_geom():
     so, src = HG / "libhost_geom.so", HG / "host_geom.cpp"
     deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h",
-            ROOT / "path_planner_amd/csrc/hyas_rs.h"]
+            ROOT / "path_planner_amd/csrc/hyas_rs.h", ROOT / "path_planner_amd/csrc/hyas_flood.h"]
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
                         "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
@@ -96,6 +96,40 @@ def test_side_by_side_reeds_shepp_candidates_equal_the_plain_form(host_geom):
     x = np.concatenate([rng.uniform(-100, 100, 200000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, math.pi / 4, -math.pi / 4, 1e5, -1e5]])
     host_geom.hg_sincos_mismatches.restype = C.c_long
     assert host_geom.hg_sincos_mismatches(np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), len(x)) == 0
+
+
+def test_flood_queue_pops_like_the_reference_priority_queue(host_geom):
+    """The 2D flood's open queue restates libstdc++'s binary heap under the reference's `>=` comparator
+    (include/hybrid_a_star.h:45-53): with many equal priorities it must pop the same cell at every step."""
+    rng = np.random.default_rng(3)
+    host_geom.hg_heap_mismatches.restype = C.c_long
+    for n, levels in ((2000, 3), (50000, 40), (50000, 100000), (300, 1)):
+        prio = np.ascontiguousarray(rng.integers(0, levels, n).astype(np.float32) * np.float32(0.25))
+        is_pop = np.ascontiguousarray((rng.random(n) < 0.45).astype(np.uint8))
+        assert host_geom.hg_heap_mismatches(prio.ctypes.data_as(C.c_void_p), is_pop.ctypes.data_as(C.c_void_p), n) == 0
+
+
+@pytest.mark.parametrize("case", [("map_maze", 1.0, 0.0, 0.0), ("map_parking", 1.0, 0.0, 0.0), ("map_large", 1.0, 0.0, 0.0),
+                                  ("map_basic", 0.5, -3.25, 2.5), ("map_small", 0.3, 1.7, -0.4)])
+def test_flood_algorithm_matches_oracle(case, host_geom, oracle_built):
+    """The flood kernel's formulation (parent index per cell, edge added at pop time from stored coordinates, restated
+    queue), run serially on the host, against the oracle's BuildAStarCostMap (src/hybrid_a_star.cpp:1020-1074)."""
+    name, res, ox, oy = case
+    mp = orc.load_map(name)
+    H, W = mp.shape
+    o = orc.Oracle(orc.hot_path_params(position_resolution=1))
+    o.set_costmap(mp, res, ox, oy, build_table=False)
+    rng = np.random.default_rng(11)
+    goals = np.stack([rng.uniform(ox, ox + W * res, 6), rng.uniform(oy, oy + H * res, 6)], 1).astype(np.float32)
+    goals[0] = [ox + 0.5 * res, oy + 0.5 * res]
+    goals[1] = [ox + (W - 0.01) * res, oy + (H - 0.01) * res]
+    for gx, gy in goals:
+        want = o.flood((gx, gy, 0.0))
+        got = np.zeros_like(want)
+        host_geom.hg_flood(W, H, C.c_double(res), C.c_double(ox), C.c_double(oy), C.c_float(gx), C.c_float(gy),
+                           got.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (name, gx, gy)
+        assert (want >= 0).sum() >= W * H - 1
 
 
 def test_posestamped_yaw_round_trip():
