@@ -200,6 +200,14 @@ int hyas_table_build_dev(hyas_ctx *ctx, int curve, int slice_begin, int slice_en
 /* Applies the reference's first-write-wins emplace (src/lookup_table.cpp:176,
  * :215) of all nslices raw slices into the context's keyed table. */
 int hyas_table_install_dev(hyas_ctx *ctx, int curve, const float *raw_dev);
+/* hyas_table_install_dev for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): the same first-write-wins install, with its per-key scratch (one loop rank per
+ * table key) in a static device array instead of a temporary allocation.  No counterpart in the reference.  Calls no
+ * hipMalloc / hipFree.  Limit: tables of at most HYAS_NOALLOC_MAX_KEYS keys (hyas_table_dims: (headings + 1) * w * h *
+ * position_resolution^2 + w * position_resolution), HYAS_ERANGE beyond.  All contexts on one GPU share that GPU's
+ * array: calls that overlap on one GPU race; consecutive calls are safe (every call resets the ranks it uses). */
+#define HYAS_NOALLOC_MAX_KEYS (1u << 20)
+int hyas_table_install_noalloc_dev(hyas_ctx *ctx, int curve, const float *raw_dev);
 /* replaces: LookupTable::Get{ReedsShepp,Dubins}Cost src/lookup_table.cpp:56-96
  * for n relative poses {|dx|,|dy|,dt}. */
 int hyas_table_lookup(hyas_ctx *ctx, const float *xyt, size_t n, float *cost);

@@ -68,6 +68,7 @@ EXPORTS = [
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
     "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats", "hyas_nodes_in_device_memory",
+    "hyas_table_install_noalloc_dev",
 ]
 
 _lib = None
@@ -121,6 +122,7 @@ def load_library():
     L.hyas_table_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.hyas_table_build_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.hyas_table_install_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.hyas_table_install_noalloc_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.hyas_table_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.hyas_plan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.hyas_get_path.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -284,6 +286,9 @@ class Hyas:
 
     def table_install_dev(self, curve, raw_ptr):
         self._check(self.L.hyas_table_install_dev(self.h, int(curve), C.c_void_p(raw_ptr)), "hyas_table_install_dev")
+
+    def table_install_noalloc_dev(self, curve, raw_ptr):
+        self._check(self.L.hyas_table_install_noalloc_dev(self.h, int(curve), C.c_void_p(raw_ptr)), "hyas_table_install_noalloc_dev")
 
     def table_lookup(self, xyt):
         xyt = np.ascontiguousarray(xyt, np.float32).reshape(-1, 3)

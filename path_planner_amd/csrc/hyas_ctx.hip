@@ -14,6 +14,13 @@
 
 using namespace hyas;
 
+// Scratch of hyas_table_install_noalloc_dev: one loop rank per table key (see k_table_install).  Every GPU the library
+// runs on holds its own copy of this array until the process ends; in host code the name is only a handle for
+// hipGetSymbolAddress, the address the kernels get is taken per device in hyas_create.
+static __device__ __align__(256) uint32_t scratch[HYAS_NOALLOC_MAX_KEYS];
+#define HYAS_MAX_DEVICES 64
+static uint32_t *scratch_ptr[HYAS_MAX_DEVICES] = {nullptr}; // device address of `scratch`, by device ordinal
+
 namespace hyas
 {
 
@@ -576,6 +583,18 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     }
     if (hipSetDevice(device) != hipSuccess)
         return nullptr;
+    if (device < HYAS_MAX_DEVICES && !scratch_ptr[device])
+    {
+        // this device's copy of the static scratch array (the device is current)
+        uint32_t *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+        {
+            fprintf(stderr, "hyas_create: hipGetSymbolAddress(scratch) failed on device %d: %s\n", device, hipGetErrorString(e));
+            return nullptr;
+        }
+        scratch_ptr[device] = p;
+    }
     hyas_ctx *c = new hyas_ctx();
     c->P = *params;
     c->device = device;
@@ -718,6 +737,37 @@ int hyas_table_install_dev(hyas_ctx *c, int curve, const float *raw_dev)
     (void)hipFree(rank);
     HYAS_HIP(c, e);
     c->dm.table_miss = (curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f; // src/lookup_table.cpp:59, :85
+    c->have_table = true;
+    return HYAS_OK;
+}
+
+int hyas_table_install_noalloc_dev(hyas_ctx *c, int curve, const float *raw_dev)
+{
+    if (!c || !c->have_map)
+        return HYAS_ESTATE;
+    if (c->grid_only || !c->d_table)
+        return c->fail(HYAS_ESTATE, "the heuristic table needs hyas_set_costmap, not hyas_set_grid");
+    if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
+        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
+    if (!raw_dev)
+        return c->fail(HYAS_EINVAL, "null table");
+    if (c->table_size > HYAS_NOALLOC_MAX_KEYS)
+    {
+        char buf[200];
+        snprintf(buf, sizeof buf, "hyas_table_install_noalloc_dev: the table has %llu keys, the static scratch holds %u; use hyas_table_install_dev",
+                 (unsigned long long)c->table_size, HYAS_NOALLOC_MAX_KEYS);
+        return c->fail(HYAS_ERANGE, buf);
+    }
+    uint32_t *rank = c->device < HYAS_MAX_DEVICES ? scratch_ptr[c->device] : nullptr;
+    if (!rank)
+        return c->fail(HYAS_ENODEV, "no static scratch on this device");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    // launch_table_install starts by setting every rank the table can address to "no position yet"
+    launch_table_install(c->dm, raw_dev, c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts,
+                         (uint32_t)c->tab_ts.size(), rank, c->d_table, c->table_size, c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    c->dm.table_miss = (curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
     c->have_table = true;
     return HYAS_OK;
 }
