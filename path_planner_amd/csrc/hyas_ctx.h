@@ -20,6 +20,7 @@ struct hyas_ctx
     hyas_params P{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t prep_stream = nullptr; // set-up of the next chunk of a large batch, beside the rounds of the current one
     // search rounds: up to HYAS_MAX_GROUPS query groups in flight, one stream each (round_stream[0] is `stream`)
     // and a begin/end event pair around the group's kernel
     hipStream_t round_stream[HYAS_MAX_GROUPS] = {};
@@ -117,7 +118,7 @@ void free_search_pools(hyas_ctx *c);
 // 2D flood of `nq` queries on the GPU (see k_flood): poses6_dev / qlist_dev / twod_dev / start_cost_dev are device
 // pointers; launches on `s` and returns without waiting
 int flood_dev(hyas_ctx *c, const float *poses6_dev, const uint32_t *qlist_dev, uint32_t nq, float *twod_dev, float *start_cost_dev,
-              hipStream_t s);
+              hipStream_t s, int max_per_cu = 0);
 void timer_begin(hyas_ctx *c);
 void timer_end(hyas_ctx *c, int which); // call after the stream has been synchronised
 void reset_timers(hyas_ctx *c);

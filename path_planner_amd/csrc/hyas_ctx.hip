@@ -82,14 +82,14 @@ int ensure_buffer(hyas_ctx *c, void **buf, size_t *have, size_t bytes)
     return HYAS_OK;
 }
 
-int flood_dev(hyas_ctx *c, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod, float *start_cost, hipStream_t s)
+int flood_dev(hyas_ctx *c, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod, float *start_cost, hipStream_t s, int max_per_cu)
 {
     if (!nq)
         return HYAS_OK;
     int cap_override = 0;
     if (const char *e = std::getenv("HYAS_FLOOD_HEAP")) // test knob: a tiny queue in LDS sends the rest through the spill area
         cap_override = std::max(1, std::atoi(e));
-    const FloodPlan fp = plan_flood((uint32_t)c->twod_size, nq, cap_override);
+    const FloodPlan fp = plan_flood((uint32_t)c->twod_size, nq, cap_override, max_per_cu);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_xy = 0, o_heap = up(fp.ws_xy_bytes), o_g = o_heap + up(fp.ws_heap_bytes), o_ps = o_g + up(fp.ws_g_bytes),
                  total = o_ps + up(fp.ws_ps_bytes);
@@ -627,6 +627,8 @@ void hyas_destroy(hyas_ctx *c)
     for (int g = 0; g < HYAS_MAX_GROUPS; ++g) // round_stream[0] is c->stream
         if (c->round_stream[g])
             (void)hipStreamSynchronize(c->round_stream[g]);
+    if (c->prep_stream)
+        (void)hipStreamSynchronize(c->prep_stream);
     free_map(c);
     if (c->d_flood_ws)
         (void)hipFree(c->d_flood_ws);
@@ -654,6 +656,8 @@ void hyas_destroy(hyas_ctx *c)
         if (g > 0 && c->round_stream[g])
             (void)hipStreamDestroy(c->round_stream[g]);
     }
+    if (c->prep_stream)
+        (void)hipStreamDestroy(c->prep_stream);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;

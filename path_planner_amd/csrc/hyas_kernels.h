@@ -45,7 +45,8 @@ struct FloodPlan
     bool narrow, cells_in_lds;
     size_t lds_bytes, ws_xy_bytes, ws_heap_bytes, ws_g_bytes, ws_ps_bytes;
 };
-FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override);
+// max_per_cu > 0 caps the workgroups per compute unit (1: the LDS request is padded so that no second one fits)
+FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override, int max_per_cu = 0);
 // poses6: n x {start x, y, t, goal x, y, t}; qlist: which queries to flood (null: 0..nq-1); twod: [query][n_cells];
 // start_cost (optional): the cost at each query's start cell, -1 if the flood never closed it.
 hipError_t launch_flood(const DevMap &m, const FloodPlan &fp, const float *poses6, const uint32_t *qlist, uint32_t nq, float *twod,

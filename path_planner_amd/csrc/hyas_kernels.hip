@@ -21,6 +21,10 @@
 namespace hyas
 {
 
+// LDS pointers carry their address space: through generic pointers every access would be a flat load that waits for
+// both memory counters.
+#define HYAS_LDS __attribute__((address_space(3)))
+
 // ------------------------------------------------------------------ collision
 __global__ void __launch_bounds__(256) k_collision_polygon(DevMap m, const float *__restrict__ xyt,
                                                            const float *__restrict__ pred_xy, size_t n,
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(1024) k_collision_footprint_tiles(DevMap m, co
 // 8-byte gather each, usually a single one: the lists are short and an 8 x 8 tile is wide), the box's rows are cut
 // out of them and ANDed with the bitmap.  A listed cell off the grid reads as occupied (tile bits beyond the grid
 // are 1, tiles beyond the grid all ones), which is the verdict the per-cell test gives.
-// Four poses per thread and iteration: three 16-byte pose loads, requested one iteration ahead, one 4-byte store.
+// Four poses per thread and iteration, one 4-byte verdict store.
 template <int BB>
 __global__ void __launch_bounds__(BB <= 5 ? 512 : 1024) k_collision_footprint_window(DevMap m, const float *__restrict__ xyt, size_t n,
                                                                                      uint8_t *__restrict__ out)
@@ -166,26 +170,32 @@ __global__ void __launch_bounds__(BB <= 5 ? 512 : 1024) k_collision_footprint_wi
     const int pr = m.pr;
     const size_t groups = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 *src = reinterpret_cast<const f32x4 *>(xyt);
-    f32x4 a = {0, 0, 0, 0}, b = a, c = a;
-    if (g < groups)
+    // A wave reads the 3 KB of its 256 poses as three fully contiguous 1 KB loads, parks them in its own strip of
+    // LDS and every lane takes its four poses (48 bytes) back out of it: lane-strided 16-byte loads straight from
+    // memory touch every cache line three times (measured 31 vs 24 us for the pose stream alone).
+    HYAS_LDS f32x4 *strip = (HYAS_LDS f32x4 *)(s_win + ((m.fp_entries * WORDS + 3u) & ~3u)) + (threadIdx.x >> 6) * 192;
+    const int lane = threadIdx.x & 63;
+    for (size_t w0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) & ~(size_t)63; w0 < groups; w0 += stride)
     {
-        a = __builtin_nontemporal_load(src + 3 * g);
-        b = __builtin_nontemporal_load(src + 3 * g + 1);
-        c = __builtin_nontemporal_load(src + 3 * g + 2);
-    }
-    while (g < groups)
-    {
-        const size_t gn = g + stride;
-        f32x4 na = {0, 0, 0, 0}, nb = na, nc = na;
-        if (gn < groups)
+        const size_t g = w0 + lane;
+        f32x4 a = {0, 0, 0, 0}, b = a, c = a;
+        if (w0 + 64 <= groups) // uniform across the wave
         {
-            na = __builtin_nontemporal_load(src + 3 * gn);
-            nb = __builtin_nontemporal_load(src + 3 * gn + 1);
-            nc = __builtin_nontemporal_load(src + 3 * gn + 2);
+            f32x4 l[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                l[j] = __builtin_nontemporal_load(src + 3 * w0 + j * 64 + lane);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                strip[j * 64 + lane] = l[j];
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the strip is the wave's own: order, no barrier
+            a = strip[3 * lane], b = strip[3 * lane + 1], c = strip[3 * lane + 2];
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        else if (g < groups)
+            a = src[3 * g], b = src[3 * g + 1], c = src[3 * g + 2];
         const float px[4] = {a.x, a.w, b.z, c.y}, py[4] = {a.y, b.x, b.w, c.z}, pt[4] = {a.z, b.y, c.x, c.w};
         uint32_t win[4][WORDS];
         uint64_t tile[4][4];
@@ -272,9 +282,8 @@ __global__ void __launch_bounds__(BB <= 5 ? 512 : 1024) k_collision_footprint_wi
             }
             v |= (in_table[k] && hit == 0) ? 1u << (8 * k) : 0u;
         }
-        __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(out + 4 * g));
-        a = na, b = nb, c = nc;
-        g = gn;
+        if (g < groups)
+            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(out + 4 * g));
     }
     // the last n % 4 poses
     if (blockIdx.x == 0 && threadIdx.x < (n & 3))
@@ -469,7 +478,6 @@ __device__ __forceinline__ uint32_t count_samples_db(const float *__restrict__ s
 
 // Quads from the workgroup's LDS copy when there is one, else from global memory.  The LDS pointers carry their
 // address space: through generic pointers every access would be a flat load that waits for both memory counters.
-#define HYAS_LDS __attribute__((address_space(3)))
 struct StepQuads
 {
     const HYAS_LDS Quad *lds; // valid when local
@@ -1353,26 +1361,23 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
     if (mode == HYAS_MODE_FOOTPRINT && m.fp_win && m.occ_tiles && (m.fp_bb == 5 || m.fp_bb == 7 || m.fp_bb == 9) && !force_packed_lists)
     {
         // persistent grid: as many workgroups as fit on the chip, grid-stride over groups of four poses
-        const size_t lds = (size_t)m.fp_entries * m.fp_win_words * sizeof(uint32_t);
         const int threads = m.fp_bb <= 5 ? 512 : 1024;
+        const size_t lds = (((size_t)m.fp_entries * m.fp_win_words + 3) & ~(size_t)3) * sizeof(uint32_t) + (size_t)(threads / 64) * 192 * 16;
         // workgroups resident per compute unit: the registers allow four waves per SIMD
         const int per_cu = std::max(1, std::min<int>(1024 / threads, (int)((160 * 1024 - 512) / std::max<size_t>(lds, 1))));
         const int blocks = (int)std::max<size_t>(1, std::min<size_t>((size_t)256 * per_cu, (n / 4 + threads - 1) / threads));
+        static size_t lds_set[3] = {0, 0, 0}; // dynamic LDS limit each variant was last given
+        auto go = [&](auto kernel, int slot) {
+            if (lds_set[slot] < lds && hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+                lds_set[slot] = lds;
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
+        };
         if (m.fp_bb == 5)
-        {
-            (void)hipFuncSetAttribute((const void *)k_collision_footprint_window<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_collision_footprint_window<5>, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
-        }
+            go(k_collision_footprint_window<5>, 0);
         else if (m.fp_bb == 7)
-        {
-            (void)hipFuncSetAttribute((const void *)k_collision_footprint_window<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_collision_footprint_window<7>, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
-        }
+            go(k_collision_footprint_window<7>, 1);
         else
-        {
-            (void)hipFuncSetAttribute((const void *)k_collision_footprint_window<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_collision_footprint_window<9>, dim3(blocks), dim3(threads), lds, s, m, xyt, n, out);
-        }
+            go(k_collision_footprint_window<9>, 2);
     }
     else if (mode == HYAS_MODE_FOOTPRINT && m.fp_pack && m.occ_tiles)
     {
@@ -1505,7 +1510,7 @@ void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hy
 // Plans the launch of k_flood for maps of n_cells cells: how many workgroups (= workspace slots), how much LDS, and
 // which variant.  Cells live in LDS when {cost, parent | state} of every cell plus a queue of at least 256 entries fit;
 // the queue gets what is left of an equal share of the compute unit's LDS, so that several queries run per unit.
-FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override)
+FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override, int max_per_cu)
 {
     FloodPlan fp{};
     fp.n_cells = n_cells;
@@ -1519,6 +1524,8 @@ FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override
     size_t heap_cap = 1024;
     for (int k : {8, 4, 2, 1})
     {
+        if (max_per_cu > 0 && k > max_per_cu)
+            continue;
         const size_t budget = lds_total / k - margin;
         if (cell_bytes + 256 * 16 <= budget)
         {
@@ -1533,7 +1540,11 @@ FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override
     if (heap_cap_override > 0)
         heap_cap = (size_t)heap_cap_override;
     fp.heap_cap = (uint32_t)heap_cap;
+    if (max_per_cu > 0)
+        per_cu = std::min(per_cu, max_per_cu);
     fp.lds_bytes = heap_cap * 16 + (fp.cells_in_lds ? cell_bytes : 0);
+    if (max_per_cu == 1)
+        fp.lds_bytes = std::max<size_t>(fp.lds_bytes, lds_total / 2 + margin); // no second workgroup on the unit
     fp.grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_queries, (size_t)256 * per_cu));
     fp.ws_xy_bytes = (size_t)fp.grid * n_cells * sizeof(float2);
     fp.ws_heap_bytes = (size_t)fp.grid * n_cells * sizeof(uint4);

@@ -618,7 +618,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
             (void)hipGetLastError(), free_b = (size_t)8 << 30;
-        const size_t per_query = twod * sizeof(float) + 4096;
+        const size_t per_query = 2 * twod * sizeof(float) + 4096; // two sets of cost maps when chunks are pipelined
         const size_t reuse = c->d_twod_bytes; // already held by this context
         chunk_cap = std::min<size_t>(chunk_cap, std::max<size_t>(16, (free_b / 4 + reuse) / per_query));
     }
@@ -656,48 +656,86 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         return rc;
     };
 
-    for (size_t base = 0; base < n; base += chunk_cap)
+    // ---- staging, laid out once for the largest chunk (one pinned block, one device block) ----
+    const size_t cn_max = std::min(chunk_cap, n);
+    // the next chunk is set up while this one's rounds run: two sets of set-up buffers (HYAS_PIPELINE=0: one after the other)
+    const bool pipelined = n > chunk_cap && !(std::getenv("HYAS_PIPELINE") && std::atoi(std::getenv("HYAS_PIPELINE")) == 0);
+    const int n_bufs = pipelined ? 2 : 1;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
+    auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
+    const int spec_k = spec_cfg;
+    const size_t KS = (size_t)spec_k;
+    // groups of a chunk hold ceil(cn / groups) queries each: at most cn + groups slots in all
+    const size_t slots_max = cn_max + HYAS_MAX_GROUPS;
+    const size_t o_in = take(slots_max * KS * sizeof(StepIn));
+    const size_t o_succ = take(res_stride(slots_max * KS) + HYAS_MAX_GROUPS * 512);
+    // set-up staging, per buffer set: goals, poses {start, goal}, relative poses for the table lookup, their results
+    struct PrepOff
     {
-        const size_t cn = std::min(chunk_cap, n - base);
-        const auto wall0 = std::chrono::steady_clock::now();
-        auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
-        std::vector<Query> Q(cn);
+        size_t goal, poses, rel, cost, ok, qlist, startc;
+    } po[2];
+    for (int bset = 0; bset < n_bufs; ++bset)
+    {
+        po[bset].goal = take(cn_max * sizeof(hyas_goal)), po[bset].poses = take(cn_max * 6 * sizeof(float));
+        po[bset].rel = take(cn_max * 3 * sizeof(float)), po[bset].cost = take(cn_max * sizeof(float));
+        po[bset].ok = take(cn_max * 2 + 4), po[bset].qlist = take(cn_max * sizeof(uint32_t)), po[bset].startc = take(cn_max * sizeof(float));
+    }
+    int rc = ensure_scratch(c, off, off);
+    if (rc != HYAS_OK)
+        return rc;
+    const size_t twod_stride = (cn_max * twod + 63) & ~(size_t)63; // floats per buffer set
+    if ((rc = ensure_twod(c, (size_t)n_bufs * twod_stride * sizeof(float))) != HYAS_OK)
+        return rc;
+    char *const hs = (char *)c->h_scratch, *const ds = (char *)c->d_scratch;
+    StepIn *const h_in = (StepIn *)(hs + o_in);
+    char *hd = nullptr; // the pinned host block as the GPU addresses it
+    HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
+    // the popped nodes go into device memory the host can store into, where there is such memory, else into the
+    // pinned host block; r_in: where the host writes them, k_in: where the kernel reads them
+    if ((rc = ensure_nodes(c, slots_max * KS * sizeof(StepIn))) != HYAS_OK)
+        return rc;
+    StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
+    const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
+    if (!c->prep_stream)
+    {
+        // lowest priority: streams of another priority get a hardware queue of their own (the round streams share the
+        // process's four queues, and a flood that runs for a large part of a second must not sit in front of them)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+            (void)hipGetLastError(), least = 0;
+        if (hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, least) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            HYAS_HIP(c, hipStreamCreate(&c->prep_stream));
+        }
+    }
 
-        // staging layout (one pinned block, one device block)
-        size_t off = 0;
-        auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
-        auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-        const size_t want_groups = n_groups ? n_groups : (cn <= 2048 ? 4 : 8);
-        const int ng = (int)std::max<size_t>(1, std::min<size_t>(want_groups, cn / 32 + 1));
-        const size_t gcap = (cn + ng - 1) / ng; // queries per group
-        const int spec_k = spec_cfg;
-        const size_t KS = (size_t)spec_k;
-        const size_t o_in = take(cn * KS * sizeof(StepIn));
-        const int max_drivers = drivers_cfg ? drivers_cfg : std::max(1, ng / 2);
-        const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
-        const int threads_per_driver =
-            (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
-        const size_t o_succ = take(ng * res_stride(gcap * KS));
-        const size_t o_goal = take(cn * sizeof(hyas_goal));
-        // set-up staging: poses {start, goal}, relative poses for the table lookup, their results
-        const size_t o_poses = take(cn * 6 * sizeof(float)), o_rel = take(cn * 3 * sizeof(float)), o_cost = take(cn * sizeof(float)),
-                     o_ok = take(cn * 2 + 4), o_qlist = take(cn * sizeof(uint32_t)), o_startc = take(cn * sizeof(float));
-        int rc = ensure_scratch(c, off, off);
-        if (rc != HYAS_OK)
-            return rc;
-        if ((rc = ensure_twod(c, cn * twod * sizeof(float))) != HYAS_OK)
-            return rc;
-        char *hs = (char *)c->h_scratch, *ds = (char *)c->d_scratch;
-        StepIn *h_in = (StepIn *)(hs + o_in);
-        hyas_goal *h_goal = (hyas_goal *)(hs + o_goal);
-
+    // ---- set-up of one chunk: pose checks, table lookups, 2D floods, start nodes ----
+    struct Prep
+    {
+        size_t base = 0, cn = 0;
+        int buf = 0, rc = HYAS_OK;
+        std::vector<Query> Q;
+        double t_gpu = 0, t_all = 0;
+    };
+    auto prepare = [&](Prep &P, bool overlapped) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t cn = P.cn, base = P.base;
+        const PrepOff &o = po[P.buf];
+        hipStream_t st = c->prep_stream;
+        P.Q.clear();
+        P.Q.resize(cn);
+        std::vector<Query> &Q = P.Q;
+        hyas_goal *h_goal = (hyas_goal *)(hs + o.goal);
         // makePlan pre-checks (src/hybrid_a_star_planner.cpp:126-155): start and goal poses through the pose test;
         // the start node's curve cost (:63) from the heuristic table: both on the GPU, in one trip
-        float *poses = (float *)(hs + o_poses), *rel = (float *)(hs + o_rel), *cost = (float *)(hs + o_cost),
-              *start_cost = (float *)(hs + o_startc);
-        uint8_t *pose_ok = (uint8_t *)(hs + o_ok);
-        uint32_t *qlist = (uint32_t *)(hs + o_qlist);
+        float *poses = (float *)(hs + o.poses), *rel = (float *)(hs + o.rel), *cost = (float *)(hs + o.cost),
+              *start_cost = (float *)(hs + o.startc);
+        uint8_t *pose_ok = (uint8_t *)(hs + o.ok);
+        uint32_t *qlist = (uint32_t *)(hs + o.qlist);
         for (size_t i = 0; i < cn; ++i)
         {
             const float *s = starts + 3 * (base + i), *g = goals + 3 * (base + i);
@@ -708,12 +746,12 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             h_goal[i] = hyas_goal{p[3], p[4], p[5]};
             rel[3 * i] = hy_fabsf(p[3] - p[0]), rel[3 * i + 1] = hy_fabsf(p[4] - p[1]), rel[3 * i + 2] = p[5] - p[2];
         }
-        HYAS_HIP(c, hipMemcpyAsync(ds + o_goal, hs + o_goal, o_cost - o_goal, hipMemcpyHostToDevice, c->stream)); // goals, poses, rel
-        launch_collision(m, HYAS_MODE_POLYGON, (const float *)(ds + o_poses), nullptr, cn * 2, (uint8_t *)(ds + o_ok), c->stream);
-        launch_table_lookup(m, (const float *)(ds + o_rel), cn, (float *)(ds + o_cost), c->stream);
+        HYAS_HIP(c, hipMemcpyAsync(ds + o.goal, hs + o.goal, o.cost - o.goal, hipMemcpyHostToDevice, st)); // goals, poses, rel
+        launch_collision(m, HYAS_MODE_POLYGON, (const float *)(ds + o.poses), nullptr, cn * 2, (uint8_t *)(ds + o.ok), st);
+        launch_table_lookup(m, (const float *)(ds + o.rel), cn, (float *)(ds + o.cost), st);
         HYAS_HIP(c, hipGetLastError());
-        HYAS_HIP(c, hipMemcpyAsync(hs + o_cost, ds + o_cost, o_qlist - o_cost, hipMemcpyDeviceToHost, c->stream)); // costs, verdicts
-        HYAS_HIP(c, hipStreamSynchronize(c->stream));
+        HYAS_HIP(c, hipMemcpyAsync(hs + o.cost, ds + o.cost, o.qlist - o.cost, hipMemcpyDeviceToHost, st)); // costs, verdicts
+        HYAS_HIP(c, hipStreamSynchronize(st));
         size_t n_flood = 0;
         for (size_t i = 0; i < cn; ++i)
         {
@@ -736,19 +774,21 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             qlist[n_flood++] = (uint32_t)i;
         }
         // 2D cost map of every goal (src/hybrid_a_star.cpp:59), on the GPU, straight into the buffer the round kernel
-        // reads; the host only needs the cost at each start cell
+        // reads; the host only needs the cost at each start cell.  Beside the rounds of another chunk the flood keeps to
+        // one workgroup per compute unit, so that the round kernels still find LDS on every unit.
         if (n_flood)
         {
-            HYAS_HIP(c, hipMemcpyAsync(ds + o_qlist, qlist, n_flood * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            if ((rc = flood_dev(c, (const float *)(ds + o_poses), (const uint32_t *)(ds + o_qlist), (uint32_t)n_flood, c->d_twod,
-                                (float *)(ds + o_startc), c->stream)) != HYAS_OK)
-                return rc;
-            HYAS_HIP(c, hipMemcpyAsync(start_cost, ds + o_startc, cn * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            HYAS_HIP(c, hipStreamSynchronize(c->stream));
+            HYAS_HIP(c, hipMemcpyAsync(ds + o.qlist, qlist, n_flood * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            int frc = flood_dev(c, (const float *)(ds + o.poses), (const uint32_t *)(ds + o.qlist), (uint32_t)n_flood,
+                                c->d_twod + (size_t)P.buf * twod_stride, (float *)(ds + o.startc), st, overlapped ? 1 : 0);
+            if (frc != HYAS_OK)
+                return frc;
+            HYAS_HIP(c, hipMemcpyAsync(start_cost, ds + o.startc, cn * sizeof(float), hipMemcpyDeviceToHost, st));
+            HYAS_HIP(c, hipStreamSynchronize(st));
         }
-        const double wall_flood = since(wall0);
+        P.t_gpu = since(t0);
         // per-query set-up: search structures and the start node (:61-78)
-        pool.run(n_flood, [&](size_t a, size_t b) {
+        auto init = [&](size_t a, size_t b) {
             for (size_t k = a; k < b; ++k)
             {
                 const size_t i = qlist[k];
@@ -764,16 +804,62 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 CellMap::Slot &cell = q.cells.get(idx);
                 cell.g = q.start.g, cell.open = 1, cell.closed = 0;
             }
-        });
+        };
+        if (overlapped) // the worker pools are busy with the other chunk's rounds
+            init(0, n_flood);
+        else
+            pool.run(n_flood, init);
+        P.t_all = since(t0);
+        return HYAS_OK;
+    };
 
-        char *hd = nullptr; // the pinned host block as the GPU addresses it
-        HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
-        // the popped nodes go into device memory the host can store into, where there is such memory, else into the
-        // pinned host block; r_in: where the host writes them, k_in: where the kernel reads them
-        if ((rc = ensure_nodes(c, cn * KS * sizeof(StepIn))) != HYAS_OK)
-            return rc;
-        StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
-        const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
+    Prep cur, nxt;
+    cur.base = 0, cur.cn = std::min(chunk_cap, n), cur.buf = 0;
+    if ((rc = prepare(cur, false)) != HYAS_OK)
+        return rc;
+    for (;;)
+    {
+        const auto wall0 = std::chrono::steady_clock::now();
+        const size_t cn = cur.cn, base = cur.base;
+        std::vector<Query> &Q = cur.Q;
+        const size_t o_goal = po[cur.buf].goal;
+        const float *const d_twod_cur = c->d_twod + (size_t)cur.buf * twod_stride;
+        // the next chunk's set-up runs on a thread of its own (own stream, own buffers) while this chunk's rounds run
+        const bool has_next = base + cn < n;
+        std::thread prep_thread;
+        struct Joiner
+        {
+            std::thread &t;
+            ~Joiner()
+            {
+                if (t.joinable())
+                    t.join();
+            }
+        } joiner{prep_thread};
+        if (has_next)
+        {
+            nxt = Prep();
+            nxt.base = base + cn, nxt.cn = std::min(chunk_cap, n - nxt.base), nxt.buf = pipelined ? 1 - cur.buf : 0;
+        }
+        if (has_next && pipelined)
+        {
+            prep_thread = std::thread([&] {
+                if (hipSetDevice(c->device) != hipSuccess)
+                {
+                    nxt.rc = HYAS_ENODEV;
+                    return;
+                }
+                nxt.rc = prepare(nxt, true);
+            });
+        }
+        const size_t want_groups = n_groups ? n_groups : (cn <= 2048 ? 4 : 8);
+        const int ng = (int)std::max<size_t>(1, std::min<size_t>(want_groups, cn / 32 + 1));
+        const size_t gcap = (cn + ng - 1) / ng; // queries per group
+        const int max_drivers = drivers_cfg ? drivers_cfg : std::max(1, ng / 2);
+        const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
+        const int threads_per_driver =
+            (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
+        const double wall_flood = cur.t_gpu;
 
         // rounds.  The chunk's queries form groups that advance independently: every group has its own stream and
         // slice of the staging block; up to four driver threads (with helper threads) each look after a share of
@@ -922,7 +1008,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             if (c->d_nodes)
                 __builtin_ia32_sfence(); // the stores into device memory leave the write-combining buffers before the doorbell
             (void)hipEventRecord(ev[0], st);
-            launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), c->d_twod, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
+            launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
                          (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
                          c->stats_mode, st);
             (void)hipEventRecord(ev[1], st);
@@ -975,7 +1061,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
             }
         };
-        const double wall_setup = since(wall0);
+        const double wall_setup = cur.t_all;
         c->pools->driver_pools(n_drivers, threads_per_driver);
         {
             std::vector<std::thread> drivers;
@@ -985,7 +1071,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             for (auto &t : drivers)
                 t.join();
         }
-        const double wall_rounds = since(wall0) - wall_setup;
+        const double wall_rounds = since(wall0);
         double t_host = 0, t_launch = 0, t_wait = 0;
         for (int gi = 0; gi < ng; ++gi)
         {
@@ -1065,8 +1151,20 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             c->expanded[base + i].swap(Q[i].expanded);
         }
         if (trace_on)
-            fprintf(stderr, "hyas chunk of %zu queries: %.3f s in all, %.3f s after the rounds\n", cn, since(wall0),
-                    since(wall0) - wall_setup - wall_rounds);
+            fprintf(stderr, "hyas chunk of %zu queries: set-up %.3f s%s, rounds and finish %.3f s, %.3f s after the rounds\n", cn, wall_setup,
+                    base ? " (beside the previous chunk's rounds)" : "", since(wall0), since(wall0) - wall_rounds);
+        if (!has_next)
+            break;
+        if (pipelined)
+            prep_thread.join();
+        else
+        {
+            Q.clear();
+            nxt.rc = prepare(nxt, false);
+        }
+        if (nxt.rc != HYAS_OK)
+            return nxt.rc;
+        cur = std::move(nxt);
     }
     return HYAS_OK;
 }
