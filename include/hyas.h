@@ -69,6 +69,18 @@ typedef struct hyas_params
     double fp_width;                  /* 0.18 */
     double fp_length;                 /* 0.22 */
     float fp_cell_size;               /* 1 */
+    /* path post-processing and the remaining ParameterHybridAStar / ParameterCollisionDetection switches
+     * (include/parameter_manager.h:28-40, :128, :162, :170-172) */
+    int32_t short_cut;                /* 1: HybridAStar::ShortCut on the traced path */
+    float max_steering_angle;         /* 30 */
+    int32_t consider_steering_angle_range_for_obstacle_density;                  /* 0 */
+    int32_t add_one_more_successor_only_in_free_angle_range;                     /* 0 */
+    int32_t add_one_more_successor;                                              /* 1 */
+    int32_t steering_angle_towards_free_angle_range_for_obstacle_angle_range;    /* 1 */
+    int32_t fixed_number_of_steering_angle_in_free_angle_range;                  /* 1 */
+    float constant_density;           /* 0.5 */
+    int32_t piecewise_cubic_bezier_interpolation; /* 0 (only 0 is supported) */
+    float curve_step_size;            /* 1 */
     int32_t reserved;
 } hyas_params;
 
@@ -219,6 +231,14 @@ int hyas_table_lookup(hyas_ctx *ctx, const float *xyt, size_t n, float *cost);
  * last batch stay in the context until the next call. */
 int hyas_plan_batch(hyas_ctx *ctx, const float *starts_xyt, const float *goals_xyt, size_t n,
                     hyas_result *out);
+/* replaces: HybridAStar::ShortCut(path, true) src/hybrid_a_star.cpp:1076-1179 (with
+ * CollisionDetection::IsTraversable(current, previous), src/collisiondetection.cpp:129-145) for n_paths
+ * independent paths.  paths_xyt: the poses {x,y,t} of all paths one after the other; path i = poses
+ * [offsets[i], offsets[i+1]).  out_idx + offsets[i] + i receives the indices (into path i) of the nodes ShortCut
+ * keeps, in path order, out_n[i] <= len_i + 1 of them.  A path of fewer than two nodes comes back unchanged (the
+ * reference reads input[size-2] there).  hyas_plan_batch applies this itself when params.short_cut is set. */
+int hyas_shortcut_batch(hyas_ctx *ctx, const float *paths_xyt, const uint32_t *offsets, size_t n_paths,
+                        uint32_t *out_idx, uint32_t *out_n);
 /* Copies min(cap, len) poses {x,y,t} / expanded idx of query i; returns len. */
 int hyas_get_path(const hyas_ctx *ctx, size_t i, float *xyt, size_t cap);
 int hyas_get_expanded(const hyas_ctx *ctx, size_t i, int32_t *idx, size_t cap);

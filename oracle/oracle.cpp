@@ -1661,6 +1661,90 @@ struct Ctx
         return true;
     }
 
+    // src/collisiondetection.cpp:129-145: both poses and the segment between them
+    bool IsTraversablePair(const Node3D &current, const Node3D &previous)
+    {
+        if (!IsOnGrid(current.x, current.y) || !IsOnGrid(previous.x, previous.y))
+            return false;
+        return configurationTest(current.x, current.y, current.t) && CollisionCheckSegment(V2{current.x, current.y}, V2{previous.x, previous.y}) &&
+               configurationTest(previous.x, previous.y, previous.t);
+    }
+    // src/utility.cpp:1288-1296 and :2111-2117
+    static float GetAngle(const Node3D &start, const Node3D &goal) { return RadToZeroTo2P(m_atan2f(goal.y - start.y, goal.x - start.x)); }
+    static float FindSteeringAngle(const Node3D &closest, const Node3D &direction)
+    {
+        float angle_between = RadNormalization(GetAngle(closest, direction));
+        return -RadNormalization(RadNormalization(closest.t) - angle_between);
+    }
+    // HybridAStar::ShortCut(path, true), src/hybrid_a_star.cpp:1076-1179, with its unsigned loop counters.  out_idx
+    // (optional) receives the input indices of the returned nodes.  The steering-angle limit it compares with is
+    // max_steering_angle = 30, a number of degrees, against an angle in radians: the test passes for every finite angle.
+    // The reference indexes input[size - 2] first, so a path of fewer than two nodes is undefined there; such a path
+    // is returned unchanged here.
+    std::vector<Node3D> ShortCut(const std::vector<Node3D> &path, std::vector<uint32_t> *out_idx = nullptr)
+    {
+        std::vector<Node3D> out, input = path;
+        std::vector<uint32_t> idx;
+        if (input.size() < 2)
+        {
+            if (out_idx)
+                for (uint32_t i = 0; i < input.size(); ++i)
+                    out_idx->push_back(i);
+            return input;
+        }
+        Node3D current_point, previous_point;
+        uint32_t previous_idx = (uint32_t)input.size() - 2;
+        float steering_angle;
+        previous_point = input[input.size() - 2];
+        for (uint32_t index1 = (uint32_t)input.size() - 1; /* index1 >= 0 */;)
+        {
+            current_point = input[index1];
+            out.emplace_back(current_point);
+            idx.push_back(index1);
+            for (uint32_t index2 = index1 - 1; /* index2 >= 0 */; index2--)
+            {
+                if (IsTraversablePair(current_point, input[index2]))
+                {
+                    previous_point = input[index2];
+                    previous_idx = index2;
+                    steering_angle = FindSteeringAngle(previous_point, current_point);
+                    if (std::abs(steering_angle) < P.max_steering_angle)
+                    {
+                        if (index2 == 0)
+                        {
+                            index1 = 0;
+                            out.emplace_back(previous_point);
+                            idx.push_back(previous_idx);
+                            break;
+                        }
+                        continue;
+                    }
+                    else
+                    {
+                        out.emplace_back(previous_point);
+                        idx.push_back(previous_idx);
+                        index1 = (index2 == 0) ? 0 : index2 - 1;
+                        break;
+                    }
+                }
+                else
+                {
+                    out.emplace_back(previous_point);
+                    idx.push_back(previous_idx);
+                    index1 = (index2 == 0) ? 0 : index2 - 1;
+                    break;
+                }
+            }
+            if (index1 == 0)
+                break;
+        }
+        std::reverse(out.begin(), out.end());
+        std::reverse(idx.begin(), idx.end());
+        if (out_idx)
+            *out_idx = idx;
+        return out;
+    }
+
     // include/node3d.h:89-98
     static bool nodeEq(const Node3D &a, const Node3D &b)
     {
@@ -1757,10 +1841,21 @@ struct Ctx
             }
             std::reverse(path.begin(), path.end());
         };
+        // GetPath's endings (:118-147): trace, RemoveDuplicates, ShortCut; calculatePath removes duplicates once more (:994)
+        auto shortcut = [&]() {
+            if (P.short_cut)
+                path = ShortCut(path);
+        };
         auto finish = [&](int status, int id) {
             res->status = status;
             res->g_final = arena[id].g;
-            RemoveDuplicates(path);
+            if (status != HYAS_STATUS_SHOT)
+            {
+                RemoveDuplicates(path);
+                shortcut();
+            }
+            else
+                RemoveDuplicates(path); // :172, after the curve was appended
             RemoveDuplicates(path); // calculatePath repeats it (:994)
             res->path_len = (int)path.size();
             double len = 0;
@@ -1828,6 +1923,7 @@ struct Ctx
                 if (shoot && analyticExpansion(nPred, goal, &shot, &slen))
                 {
                     trace(pid);
+                    shortcut(); // :165-168, before the curve is appended
                     path.insert(path.end(), shot.begin(), shot.end());
                     res->shot_length = slen;
                     finish(HYAS_STATUS_SHOT, pid);
@@ -2091,6 +2187,20 @@ int orc_plan_r(void *h, const float *start, const float *goal, hyas_result *res,
     if (exp_idx)
         std::memcpy(exp_idx, expanded.data(), std::min(exp_cap, expanded.size()) * sizeof(int32_t));
     return 0;
+}
+
+// HybridAStar::ShortCut on one path of n poses {x, y, t}; out_idx receives the input indices of the returned nodes
+// (at most n + 1 of them); returns their number.
+int orc_shortcut(void *h, const float *xyt, uint32_t n, uint32_t *out_idx)
+{
+    std::vector<orc::Node3D> path(n);
+    for (uint32_t i = 0; i < n; ++i)
+        path[i].x = xyt[3 * i], path[i].y = xyt[3 * i + 1], path[i].t = xyt[3 * i + 2];
+    std::vector<uint32_t> idx;
+    ((Ctx *)h)->ShortCut(path, &idx);
+    for (size_t i = 0; i < idx.size(); ++i)
+        out_idx[i] = idx[i];
+    return (int)idx.size();
 }
 
 int orc_get_path(void *h, float *xyt, size_t cap)

@@ -44,6 +44,16 @@ class Params(C.Structure):
         ("fp_width", C.c_double),
         ("fp_length", C.c_double),
         ("fp_cell_size", C.c_float),
+        ("short_cut", C.c_int32),
+        ("max_steering_angle", C.c_float),
+        ("consider_steering_angle_range_for_obstacle_density", C.c_int32),
+        ("add_one_more_successor_only_in_free_angle_range", C.c_int32),
+        ("add_one_more_successor", C.c_int32),
+        ("steering_angle_towards_free_angle_range_for_obstacle_angle_range", C.c_int32),
+        ("fixed_number_of_steering_angle_in_free_angle_range", C.c_int32),
+        ("constant_density", C.c_float),
+        ("piecewise_cubic_bezier_interpolation", C.c_int32),
+        ("curve_step_size", C.c_float),
         ("reserved", C.c_int32),
     ]
 
@@ -68,7 +78,7 @@ EXPORTS = [
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
     "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats", "hyas_nodes_in_device_memory",
-    "hyas_table_install_noalloc_dev",
+    "hyas_table_install_noalloc_dev", "hyas_shortcut_batch",
 ]
 
 _lib = None
@@ -125,6 +135,7 @@ def load_library():
     L.hyas_table_install_noalloc_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.hyas_table_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.hyas_plan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.hyas_shortcut_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.hyas_get_path.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.hyas_get_expanded.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.hyas_last_kernel_ms.restype = C.c_double
@@ -306,6 +317,16 @@ class Hyas:
         res = np.zeros(n, RESULT_DT)
         self._check(self.L.hyas_plan_batch(self.h, _vp(starts), _vp(goals), n, _vp(res)), "hyas_plan_batch")
         return res
+
+    def shortcut(self, paths):
+        """ShortCut for a list of [len_i, 3] pose arrays; returns the kept node indices of every path."""
+        offs = np.zeros(len(paths) + 1, np.uint32)
+        offs[1:] = np.cumsum([len(p) for p in paths])
+        allp = np.ascontiguousarray(np.concatenate(paths) if len(paths) else np.zeros((0, 3)), np.float32)
+        idx = np.zeros(int(offs[-1]) + len(paths), np.uint32)
+        cnt = np.zeros(len(paths), np.uint32)
+        self._check(self.L.hyas_shortcut_batch(self.h, _vp(allp), _vp(offs), len(paths), _vp(idx), _vp(cnt)), "hyas_shortcut_batch")
+        return [idx[int(offs[i]) + i: int(offs[i]) + i + int(cnt[i])].copy() for i in range(len(paths))]
 
     def path(self, i):
         n = self._check(self.L.hyas_get_path(self.h, int(i), None, 0), "hyas_get_path")

@@ -76,6 +76,8 @@ struct hyas_ctx
     // sampled curves of the queries an analytic shot closed (hyas_plan_batch)
     float *d_pts = nullptr;
     size_t d_pts_bytes = 0;
+    void *d_sc = nullptr; // paths, offsets and results of the shortcut kernel
+    size_t d_sc_bytes = 0;
     // host worker threads of the search driver, kept between calls (created on first use)
     hyas::SearchPools *pools = nullptr;
 
@@ -115,6 +117,8 @@ int ensure_twod(hyas_ctx *c, size_t bytes);
 int ensure_nodes(hyas_ctx *c, size_t bytes);
 int ensure_buffer(hyas_ctx *c, void **buf, size_t *have, size_t bytes); // device buffer that only grows
 void free_search_pools(hyas_ctx *c);
+// HybridAStar::ShortCut for n paths on the GPU (host pointers; layout as launch_shortcut); synchronous on c->stream
+int shortcut_paths(hyas_ctx *c, const float *paths, const uint32_t *offs, size_t n, uint32_t *out_idx, uint32_t *out_n);
 // 2D flood of `nq` queries on the GPU (see k_flood): poses6_dev / qlist_dev / twod_dev / start_cost_dev are device
 // pointers; launches on `s` and returns without waiting
 int flood_dev(hyas_ctx *c, const float *poses6_dev, const uint32_t *qlist_dev, uint32_t nq, float *twod_dev, float *start_cost_dev,

@@ -104,6 +104,30 @@ int flood_dev(hyas_ctx *c, const float *poses6, const uint32_t *qlist, uint32_t 
     return HYAS_OK;
 }
 
+int shortcut_paths(hyas_ctx *c, const float *paths, const uint32_t *offs, size_t n, uint32_t *out_idx, uint32_t *out_n)
+{
+    if (!n)
+        return HYAS_OK;
+    const size_t total = offs[n];
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_paths = 0, o_offs = up(total * 3 * sizeof(float)), o_idx = o_offs + up((n + 1) * sizeof(uint32_t)),
+                 o_n = o_idx + up((total + n) * sizeof(uint32_t)), bytes = o_n + up(n * sizeof(uint32_t));
+    int rc = ensure_buffer(c, &c->d_sc, &c->d_sc_bytes, bytes);
+    if (rc != HYAS_OK)
+        return rc;
+    char *d = (char *)c->d_sc;
+    if (total)
+        HYAS_HIP(c, hipMemcpyAsync(d + o_paths, paths, total * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HYAS_HIP(c, hipMemcpyAsync(d + o_offs, offs, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    launch_shortcut(c->dm, (const float *)(d + o_paths), (const uint32_t *)(d + o_offs), (uint32_t)n, (uint32_t *)(d + o_idx), (uint32_t *)(d + o_n),
+                    c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipMemcpyAsync(out_idx, d + o_idx, (total + n) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HYAS_HIP(c, hipMemcpyAsync(out_n, d + o_n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    return HYAS_OK;
+}
+
 // Device memory for the round kernel's input that the host writes with plain stores: fine-grained (coherent)
 // device memory on a GPU whose whole memory is visible to the CPU.  The kernel then reads its node from local
 // memory (0.5 us) instead of fetching it from host memory over PCIe (1.5-2 us).  Leaves d_nodes null where that
@@ -536,12 +560,15 @@ void hyas_default_params(hyas_params *p)
     p->penalty_turning = 1.05f, p->penalty_reverse = 1, p->penalty_change_of_direction = 2, p->reverse = 0;
     p->max_iterations = 10000, p->steering_angle = 5, p->goal_range = 1e-3f, p->tie_breaker = 0.01f;
     p->min_turning_radius = 6, p->fp_width = 0.18, p->fp_length = 0.22, p->fp_cell_size = 1;
+    p->short_cut = 1, p->max_steering_angle = 30, p->add_one_more_successor = 1;
+    p->steering_angle_towards_free_angle_range_for_obstacle_angle_range = 1, p->fixed_number_of_steering_angle_in_free_angle_range = 1;
+    p->constant_density = 0.5f, p->curve_step_size = 1;
 }
 
 void hyas_hot_path_params(hyas_params *p)
 {
     hyas_default_params(p);
-    p->curve_type = HYAS_CURVE_RS, p->number_of_successors = 5, p->steering_angle = 5, p->reverse = 1;
+    p->curve_type = HYAS_CURVE_RS, p->number_of_successors = 5, p->steering_angle = 5, p->reverse = 1, p->short_cut = 0;
 }
 
 static bool params_ok(const hyas_params *p, std::string &why)
@@ -550,6 +577,8 @@ static bool params_ok(const hyas_params *p, std::string &why)
         why = "adaptive step/steering modes are not part of this path (fixed-step branch only)";
     else if (p->map_boundary_obstacle)
         why = "map_boundary_obstacle is not supported";
+    else if (p->piecewise_cubic_bezier_interpolation)
+        why = "piecewise_cubic_bezier_interpolation is not supported";
     else if (p->headings < 1 || p->headings > 720 || p->position_resolution < 1 || p->position_resolution > 64)
         why = "headings / position_resolution out of range";
     else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS)
@@ -634,6 +663,8 @@ void hyas_destroy(hyas_ctx *c)
         (void)hipFree(c->d_flood_ws);
     if (c->d_pts)
         (void)hipFree(c->d_pts);
+    if (c->d_sc)
+        (void)hipFree(c->d_sc);
     if (c->d_scratch)
         (void)hipFree(c->d_scratch);
     if (c->h_scratch)
@@ -1185,6 +1216,29 @@ int hyas_shot_batch(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
     if (c && n && (!nodes || !goals || !ok || !len))
         return c->fail(HYAS_EINVAL, "null buffer");
     return run_step(c, nodes, goals, nullptr, n, 1, ok, len, nullptr, nullptr);
+}
+
+int hyas_shortcut_batch(hyas_ctx *c, const float *paths_xyt, const uint32_t *offsets, size_t n_paths, uint32_t *out_idx, uint32_t *out_n)
+{
+    if (!c || !c->have_map || c->grid_only)
+        return HYAS_ESTATE;
+    if (n_paths == 0)
+        return HYAS_OK;
+    if (!offsets || !out_idx || !out_n || (offsets[n_paths] && !paths_xyt))
+        return c->fail(HYAS_EINVAL, "null buffer");
+    for (size_t i = 0; i < n_paths; ++i)
+        if (offsets[i] > offsets[i + 1])
+            return c->fail(HYAS_EINVAL, "path offsets must not decrease");
+    HYAS_HIP(c, hipSetDevice(c->device));
+    std::vector<uint32_t> raw((size_t)offsets[n_paths] + n_paths);
+    int rc = shortcut_paths(c, paths_xyt, offsets, n_paths, raw.data(), out_n);
+    if (rc != HYAS_OK)
+        return rc;
+    // the kernel lists a path's nodes from its last one backwards (the order ShortCut pushes them in): reverse (:1177)
+    for (size_t i = 0; i < n_paths; ++i)
+        for (uint32_t j = 0; j < out_n[i]; ++j)
+            out_idx[(size_t)offsets[i] + i + j] = raw[(size_t)offsets[i] + i + out_n[i] - 1 - j];
+    return HYAS_OK;
 }
 
 int hyas_plan_batch(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out)

@@ -1153,6 +1153,89 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
     }
 }
 
+// -------------------------------------------------------------- path shortcut
+// HybridAStar::ShortCut(path, true) (src/hybrid_a_star.cpp:1076-1179), one path per workgroup.  From the path's last
+// node the reference walks towards its first for as long as CollisionDetection::IsTraversable(current, node)
+// (src/collisiondetection.cpp:129-145: both poses free and the segment between them) holds, keeps the last node that
+// passed, and starts again two nodes further down.  The walk of one anchor is a search for the first failing node:
+// the workgroup tests 256 candidates at a time and stops at the first chunk that holds a failure.  The steering-angle
+// test of the reference compares radians with max_steering_angle = 30 and passes for every finite angle.
+// A path of fewer than two nodes is returned unchanged (the reference reads input[size - 2] first: undefined there).
+// paths: all poses {x, y, t}, path q = poses [offs[q], offs[q + 1]); out_idx + offs[q] + q: up to len + 1 input indices in
+// the order the reference pushes them (last node first; the caller reverses), out_n[q] their number.
+__global__ void __launch_bounds__(256) k_shortcut(DevMap m, const float *__restrict__ paths, const uint32_t *__restrict__ offs, uint32_t *__restrict__ out_idx,
+                                                  uint32_t *__restrict__ out_n)
+{
+    __shared__ int s_fail, s_cur_free;
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x, base = offs[q];
+    const int n = (int)(offs[q + 1] - base);
+    const float *P = paths + 3 * (size_t)base;
+    uint32_t *out = out_idx + base + q;
+    if (n < 2)
+    {
+        if (tid == 0)
+        {
+            for (int i = 0; i < n; ++i)
+                out[i] = (uint32_t)(n - 1 - i);
+            out_n[q] = (uint32_t)n;
+        }
+        return;
+    }
+    const GlobalQuads gq{m.quads};
+    int index1 = n - 1, prev = n - 2, count = 0;
+    for (;;)
+    {
+        const float cx = P[3 * index1], cy = P[3 * index1 + 1], ct = P[3 * index1 + 2];
+        if (tid == 0)
+        {
+            out[count] = (uint32_t)index1;
+            s_fail = -1;
+            s_cur_free = (on_grid(m, cx, cy) && pose_free(m, gq, cx, cy, ct)) ? 1 : 0;
+        }
+        ++count;
+        __syncthreads();
+        int fail = -1; // highest node below index1 that is not traversable from it
+        if (!s_cur_free)
+            fail = index1 - 1;
+        else
+            for (int j0 = index1 - 1; j0 >= 0; j0 -= 256)
+            {
+                const int j = j0 - tid;
+                if (j >= 0)
+                {
+                    const float px = P[3 * j], py = P[3 * j + 1], pt = P[3 * j + 2];
+                    const bool ok = on_grid(m, px, py) && segment_free(m, gq, cx, cy, px, py) && pose_free(m, gq, px, py, pt);
+                    if (!ok)
+                        atomicMax(&s_fail, j);
+                }
+                __syncthreads();
+                fail = s_fail;
+                __syncthreads();
+                if (fail >= 0)
+                    break;
+            }
+        if (fail < 0) // every node down to the first passed (:1100-1106)
+        {
+            if (tid == 0)
+                out[count] = 0u;
+            ++count;
+            break;
+        }
+        if (fail + 1 <= index1 - 1)
+            prev = fail + 1; // the last node that passed; none: the one kept from before (:1138)
+        if (tid == 0)
+            out[count] = (uint32_t)prev;
+        ++count;
+        index1 = fail == 0 ? 0 : fail - 1;
+        if (index1 == 0)
+            break;
+        __syncthreads();
+    }
+    if (tid == 0)
+        out_n[q] = (uint32_t)count;
+}
+
 // ---------------------------------------------------- 2D cost-to-goal flood
 // HybridAStar::BuildAStarCostMap (src/hybrid_a_star.cpp:1020-1074) with AStar::CreateSuccessor(pred, 8)
 // (src/a_star.cpp:214-277, step = resolution) and AStar::UpdateCostSoFar (:281-288): a lazy Dijkstra flood from the
@@ -1494,6 +1577,12 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
         return;
     const dim3 grid(n + (n + ROUND_THREADS / 16 - 1) / (ROUND_THREADS / 16));
     HYAS_DISPATCH(k_round, grid, dim3(ROUND_THREADS), s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
+}
+
+void launch_shortcut(const DevMap &m, const float *paths, const uint32_t *offs, uint32_t n_paths, uint32_t *out_idx, uint32_t *out_n, hipStream_t s)
+{
+    if (n_paths)
+        hipLaunchKernelGGL(k_shortcut, dim3(n_paths), dim3(256), 0, s, m, paths, offs, out_idx, out_n);
 }
 
 void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,

@@ -122,6 +122,7 @@ struct Query
     bool shoot = false;
     bool done = false;
     int shot_from = -1; // >= 0: finished through an analytic shot from this node
+    int end_node = -1, end_status = 0; // >= 0: finished at this node by the goal test or the iteration limit
     hyas_result res{};
     std::vector<int32_t> expanded;
     std::vector<float> path;
@@ -288,12 +289,14 @@ struct Driver
             }
         }
     }
-    void finish(Query &q, int status, int32_t id)
+    // n_rd: how many RemoveDuplicates passes are still due (GetPath's own, unless the caller has run it in front of
+    // ShortCut, and calculatePath's, :994)
+    void finish(Query &q, int status, int32_t id, int n_rd) const
     {
         q.res.status = status;
         q.res.g_final = q.arena[id].g;
-        remove_duplicates(q.path); // GetPath, then calculatePath :994 again
-        remove_duplicates(q.path);
+        for (int i = 0; i < n_rd; ++i)
+            remove_duplicates(q.path);
         q.res.path_len = (int32_t)(q.path.size() / 3);
         double len = 0;
         for (size_t i = 1; i < q.path.size() / 3; ++i)
@@ -324,8 +327,7 @@ struct Driver
             pop(q);
             if (q.iterations > P.max_iterations)
             {
-                trace(q, pid, q.path);
-                finish(q, HYAS_STATUS_MAX_ITER, pid);
+                q.end_node = pid, q.end_status = HYAS_STATUS_MAX_ITER, q.done = true; // path assembled at the end of the chunk
                 return false;
             }
             // Utility::IsCloseEnough, src/utility.cpp:1132-1163
@@ -335,8 +337,7 @@ struct Driver
                 const float ang_range = (float)(2 * HY_PI / P.headings);
                 if (dist < dist_range && hy_fabsf(rad_norm(n.t - q.goal.t)) <= ang_range)
                 {
-                    trace(q, pid, q.path);
-                    finish(q, HYAS_STATUS_GOAL, pid);
+                    q.end_node = pid, q.end_status = HYAS_STATUS_GOAL, q.done = true;
                     return false;
                 }
             }
@@ -1087,6 +1088,51 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     "wait %.3f s; %llu expansions answered ahead of time; wall: set-up %.3f s (pose checks + 2D floods %.3f s), rounds %.3f s\n",
                     ng, n_drivers, threads_per_driver, spec_k, t_host, t_launch, t_wait, (unsigned long long)spec_hits.load(), wall_setup,
                     wall_flood, wall_rounds);
+        // paths back to the start (TracePath, :813-828), GetPath's RemoveDuplicates for the endings that have it in front
+        // of ShortCut (:121, :138), then ShortCut itself (:122-125, :139-142, :165-168) for all of them in one launch
+        {
+            std::vector<uint32_t> fin;
+            for (size_t i = 0; i < cn; ++i)
+                if (Q[i].end_node >= 0 || Q[i].shot_from >= 0)
+                    fin.push_back((uint32_t)i);
+            pool.run(fin.size(), [&](size_t a, size_t b) {
+                for (size_t k = a; k < b; ++k)
+                {
+                    Query &q = Q[fin[k]];
+                    if (q.end_node >= 0)
+                    {
+                        D.trace(q, q.end_node, q.path);
+                        Driver::remove_duplicates(q.path);
+                    }
+                    else
+                        D.trace(q, q.shot_from, q.path);
+                }
+            });
+            if (c->P.short_cut && !fin.empty())
+            {
+                std::vector<uint32_t> offs(fin.size() + 1, 0);
+                for (size_t k = 0; k < fin.size(); ++k)
+                    offs[k + 1] = offs[k] + (uint32_t)(Q[fin[k]].path.size() / 3);
+                std::vector<float> all((size_t)offs.back() * 3);
+                for (size_t k = 0; k < fin.size(); ++k)
+                    std::copy(Q[fin[k]].path.begin(), Q[fin[k]].path.end(), all.begin() + 3 * (size_t)offs[k]);
+                std::vector<uint32_t> idx((size_t)offs.back() + fin.size()), cnt(fin.size());
+                if ((rc = shortcut_paths(c, all.data(), offs.data(), fin.size(), idx.data(), cnt.data())) != HYAS_OK)
+                    return rc;
+                pool.run(fin.size(), [&](size_t a, size_t b) {
+                    std::vector<float> np;
+                    for (size_t k = a; k < b; ++k)
+                    {
+                        Query &q = Q[fin[k]];
+                        const uint32_t *ix = &idx[(size_t)offs[k] + k];
+                        np.clear();
+                        for (uint32_t j = cnt[k]; j-- > 0;) // pushed from the last node backwards; std::reverse at :1177
+                            np.insert(np.end(), q.path.begin() + 3 * (size_t)ix[j], q.path.begin() + 3 * (size_t)ix[j] + 3);
+                        q.path = np;
+                    }
+                });
+            }
+        }
         // queries closed by an analytic shot: fetch the curve samples of all of them in two launches
         // (sample counts, then the samples) (:160-172: TracePath + the sampled curve + the goal)
         {
@@ -1135,15 +1181,17 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     for (size_t k = a; k < b; ++k)
                     {
                         Query &q = Q[shot_q[k]];
-                        D.trace(q, q.shot_from, q.path);
                         q.path.insert(q.path.end(), shot_buf.begin() + 3 * (size_t)h_off[k], shot_buf.begin() + 3 * ((size_t)h_off[k] + h_cnt[k]));
                         q.path.push_back(q.goal.x), q.path.push_back(q.goal.y), q.path.push_back(q.goal.t);
-                        D.finish(q, HYAS_STATUS_SHOT, q.shot_from);
+                        D.finish(q, HYAS_STATUS_SHOT, q.shot_from, 2);
                     }
                 });
             }
         }
 
+        for (size_t i = 0; i < cn; ++i)
+            if (Q[i].end_node >= 0)
+                D.finish(Q[i], Q[i].end_status, Q[i].end_node, 1);
         for (size_t i = 0; i < cn; ++i)
         {
             out[base + i] = Q[i].res;

@@ -11,7 +11,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from ._lib import STATUS_BAD_POSE, STATUS_NO_PATH, Hyas, hot_path_params
+from ._lib import STATUS_BAD_POSE, STATUS_NO_PATH, Hyas, default_params
 
 
 @dataclass
@@ -82,7 +82,8 @@ class HybridAStarPlanner:
         self.name = name
         self.costmap = costmap
         self.frame_id_ = frame_id or costmap.frame_id
-        self._ctx = Hyas(self.params if self.params is not None else hot_path_params(), self.device)
+        # without explicit parameters: the reference's struct defaults, as its ParameterManager starts from
+        self._ctx = Hyas(self.params if self.params is not None else default_params(), self.device)
         self._ctx.set_costmap(costmap.getCharMap(), costmap.getResolution(), costmap.getOriginX(),
                               costmap.getOriginY(), build_table=True)
         self.initialized_ = True

@@ -19,13 +19,80 @@ PLUGINLIB_EXPORT_CLASS(HybridAStar::HybridAStarPlanner, nav_core::BaseGlobalPlan
 namespace HybridAStar
 {
 
-HybridAStarPlanner::HybridAStarPlanner() { hyas_hot_path_params(&params_); }
+// The struct defaults of the reference (include/parameter_manager.h:10-42, :124-175) until setParams or the ROS
+// parameter server says otherwise, as ParameterManager starts from them.
+HybridAStarPlanner::HybridAStarPlanner() { hyas_default_params(&params_); }
 
 HybridAStarPlanner::HybridAStarPlanner(std::string name, costmap_2d::Costmap2DROS *costmap_ros)
 {
-    hyas_hot_path_params(&params_);
+    hyas_default_params(&params_);
     initialize(name, costmap_ros);
 }
+
+#ifdef HYAS_HAVE_ROS
+// ParameterManager::LoadHybridAStarParams + LoadCollisionDetectionParams (src/parameter_manager.cpp:117-165, :187-252):
+// every parameter is looked up under the fixed prefix /move_base/HybridAStar/ and keeps its value when absent.
+namespace
+{
+template <typename T>
+void get_param(const std::string &name, T &value)
+{
+    ros::param::get("/move_base/HybridAStar/" + name, value);
+}
+void get_flag(const std::string &name, int32_t &value)
+{
+    bool b = value != 0;
+    ros::param::get("/move_base/HybridAStar/" + name, b);
+    value = b ? 1 : 0;
+}
+void get_float(const std::string &name, float &value)
+{
+    double d = value;
+    ros::param::get("/move_base/HybridAStar/" + name, d);
+    value = (float)d;
+}
+} // namespace
+
+void HybridAStarPlanner::loadRosParams()
+{
+    hyas_params &p = params_;
+    // ParameterCollisionDetection
+    get_float("obstacle_detection_range", p.obstacle_detection_range);
+    get_flag("map_boundary_obstacle", p.map_boundary_obstacle);
+    get_flag("consider_steering_angle_range_for_obstacle_density", p.consider_steering_angle_range_for_obstacle_density);
+    get_flag("add_one_more_successor_only_in_free_angle_range", p.add_one_more_successor_only_in_free_angle_range);
+    get_flag("steering_angle_towards_free_angle_range_for_obstacle_angle_range", p.steering_angle_towards_free_angle_range_for_obstacle_angle_range);
+    get_flag("fixed_number_of_steering_angle_in_free_angle_range", p.fixed_number_of_steering_angle_in_free_angle_range);
+    get_flag("add_one_more_successor", p.add_one_more_successor);
+    get_param("position_resolution", p.position_resolution);
+    get_param("headings", p.headings);
+    get_param("curve_type", p.curve_type);
+    get_float("vehicle_width", p.vehicle_width);
+    get_float("vehicle_length", p.vehicle_length);
+    get_float("max_steering_angle", p.max_steering_angle);
+    // "min_turning_radius" and "reverse" feed both structs (:166-170, :218-219, :233-234)
+    get_float("min_turning_radius", p.cd_min_turning_radius);
+    get_float("min_turning_radius", p.min_turning_radius);
+    get_flag("reverse", p.reverse);
+    // ParameterHybridAStar
+    get_param("number_of_successors", p.number_of_successors);
+    get_flag("adaptive_step_size", p.adaptive_step_size);
+    get_flag("piecewise_cubic_bezier_interpolation", p.piecewise_cubic_bezier_interpolation);
+    get_flag("adaptive_steering_angle_and_step_size", p.adaptive_steering_angle_and_step_size);
+    get_flag("analytical_expansion_every_point", p.analytical_expansion_every_point);
+    get_flag("analytical_expansion", p.analytical_expansion);
+    get_float("penalty_turning", p.penalty_turning);
+    get_float("penalty_reverse", p.penalty_reverse);
+    get_float("penalty_change_of_direction", p.penalty_change_of_direction);
+    get_float("steering_angle", p.steering_angle);
+    get_param("max_iterations", p.max_iterations);
+    get_float("tie_breaker", p.tie_breaker);
+    get_float("goal_range", p.goal_range);
+    get_float("curve_step_size", p.curve_step_size);
+    get_flag("short_cut", p.short_cut);
+    get_float("constant_density", p.constant_density);
+}
+#endif
 
 HybridAStarPlanner::~HybridAStarPlanner()
 {
@@ -47,6 +114,10 @@ void HybridAStarPlanner::initialize(std::string name, costmap_2d::Costmap2D *_co
     }
     costmap = _costmap;
     frame_id_ = frame_id;
+#ifdef HYAS_HAVE_ROS
+    if (!params_set_) // params_.loadRosParamFromNodeHandle(nh), src/hybrid_a_star_planner.cpp:59
+        loadRosParams();
+#endif
     ctx_ = hyas_create(&params_, device_);
     if (!ctx_)
     {
@@ -65,6 +136,7 @@ void HybridAStarPlanner::initialize(std::string name, costmap_2d::Costmap2D *_co
 #ifdef HYAS_HAVE_ROS
     ros::NodeHandle nh("~/" + name);
     plan_pub_ = nh.advertise<nav_msgs::Path>("plan", 1);
+    path_vehicles_pub_ = nh.advertise<visualization_msgs::MarkerArray>("pathVehicle", 1); // :71
     make_plan_srv_ = nh.advertiseService("make_plan", &HybridAStarPlanner::makePlanService, this);
 #else
     (void)name;
@@ -155,6 +227,36 @@ void HybridAStarPlanner::publishPlan(const std::vector<geometry_msgs::PoseStampe
 #ifdef HYAS_HAVE_ROS
     published_.header.stamp = ros::Time::now();
     plan_pub_.publish(published_);
+#endif
+}
+
+// One cube of the vehicle's size per pose (PathPublisher::AddVehicle, src/path_publisher.cpp:84-119) on ~/pathVehicle.
+// The reference hands the publisher to calculatePath (:116), which never publishes on it; callers that want the
+// markers call this after makePlan.
+void HybridAStarPlanner::publishPathNodes(const std::vector<geometry_msgs::PoseStamped> &path)
+{
+    if (!initialized_)
+        return;
+#ifdef HYAS_HAVE_ROS
+    visualization_msgs::MarkerArray vehicles;
+    int i = 0;
+    for (const geometry_msgs::PoseStamped &p : path)
+    {
+        visualization_msgs::Marker v;
+        if (i == 1)
+            v.action = 3; // delete all previous markers
+        v.header.frame_id = "map";
+        v.header.stamp = ros::Time(0);
+        v.id = i++;
+        v.type = visualization_msgs::Marker::CUBE;
+        v.scale.x = params_.vehicle_length, v.scale.y = params_.vehicle_width, v.scale.z = 1;
+        v.color.a = 0.1, v.color.r = 1, v.color.g = 0, v.color.b = 0;
+        v.pose = p.pose;
+        vehicles.markers.push_back(v);
+    }
+    path_vehicles_pub_.publish(vehicles);
+#else
+    path_nodes_published_ = path.size();
 #endif
 }
 

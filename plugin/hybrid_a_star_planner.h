@@ -18,6 +18,7 @@
 #include <nav_msgs/Path.h>
 #include <ros/ros.h>
 #include <tf/tf.h>
+#include <visualization_msgs/MarkerArray.h>
 #else
 #include "costmap_2d/costmap_2d.h"
 #include "geometry_msgs/PoseStamped.h"
@@ -45,11 +46,12 @@ class HybridAStarPlanner : public nav_core::BaseGlobalPlanner
     bool makePlan(const geometry_msgs::PoseStamped &start, const geometry_msgs::PoseStamped &goal,
                   std::vector<geometry_msgs::PoseStamped> &plan) override;
     void publishPlan(const std::vector<geometry_msgs::PoseStamped> &path);
+    void publishPathNodes(const std::vector<geometry_msgs::PoseStamped> &path); // include/hybrid_a_star_planner.h:51
     bool makePlanService(nav_msgs::GetPlan::Request &req, nav_msgs::GetPlan::Response &resp);
 
     // Additions: parameters without a ROS parameter server, the GPU to use, many queries at once, and what
     // the last makePlan did.  Call setParams / setDevice before initialize.
-    void setParams(const hyas_params &p) { params_ = p; }
+    void setParams(const hyas_params &p) { params_ = p, params_set_ = true; } // overrides the ROS parameter load
     void setDevice(int device) { device_ = device; }
     bool makePlans(const std::vector<geometry_msgs::PoseStamped> &starts, const std::vector<geometry_msgs::PoseStamped> &goals,
                    std::vector<std::vector<geometry_msgs::PoseStamped>> &plans, std::vector<hyas_result> *results = nullptr);
@@ -64,12 +66,16 @@ class HybridAStarPlanner : public nav_core::BaseGlobalPlanner
 
   private:
     hyas_params params_;
+    bool params_set_ = false;
+    size_t path_nodes_published_ = 0;
     int device_ = 0;
     hyas_ctx *ctx_ = nullptr;
     hyas_result last_{};
     nav_msgs::Path published_;
 #ifdef HYAS_HAVE_ROS
+    void loadRosParams();
     ros::Publisher plan_pub_;
+    ros::Publisher path_vehicles_pub_;
     ros::ServiceServer make_plan_srv_;
 #endif
 };

@@ -43,6 +43,16 @@ class Params(C.Structure):
         ("fp_width", C.c_double),
         ("fp_length", C.c_double),
         ("fp_cell_size", C.c_float),
+        ("short_cut", C.c_int32),
+        ("max_steering_angle", C.c_float),
+        ("consider_steering_angle_range_for_obstacle_density", C.c_int32),
+        ("add_one_more_successor_only_in_free_angle_range", C.c_int32),
+        ("add_one_more_successor", C.c_int32),
+        ("steering_angle_towards_free_angle_range_for_obstacle_angle_range", C.c_int32),
+        ("fixed_number_of_steering_angle_in_free_angle_range", C.c_int32),
+        ("constant_density", C.c_float),
+        ("piecewise_cubic_bezier_interpolation", C.c_int32),
+        ("curve_step_size", C.c_float),
         ("reserved", C.c_int32),
     ]
 
@@ -75,7 +85,11 @@ def default_params(**kw):
         adaptive_steering_angle_and_step_size=0, adaptive_step_size=0, analytical_expansion_every_point=1,
         analytical_expansion=1, penalty_turning=1.05, penalty_reverse=1.0, penalty_change_of_direction=2.0,
         reverse=0, max_iterations=10000, steering_angle=5.0, goal_range=1e-3, tie_breaker=0.01,
-        min_turning_radius=6.0, fp_width=0.18, fp_length=0.22, fp_cell_size=1.0, reserved=0,
+        min_turning_radius=6.0, fp_width=0.18, fp_length=0.22, fp_cell_size=1.0, short_cut=1, max_steering_angle=30.0,
+        consider_steering_angle_range_for_obstacle_density=0, add_one_more_successor_only_in_free_angle_range=0,
+        add_one_more_successor=1, steering_angle_towards_free_angle_range_for_obstacle_angle_range=1,
+        fixed_number_of_steering_angle_in_free_angle_range=1, constant_density=0.5, piecewise_cubic_bezier_interpolation=0,
+        curve_step_size=1.0, reserved=0,
     )
     for k, v in kw.items():
         assert hasattr(p, k), k
@@ -86,7 +100,7 @@ def default_params(**kw):
 def hot_path_params(**kw):
     """Fixed-step Reeds-Shepp configuration the benchmarks are quoted on."""
     base = dict(curve_type=1, number_of_successors=5, steering_angle=5.0, reverse=1,
-                analytical_expansion=1, analytical_expansion_every_point=1)
+                analytical_expansion=1, analytical_expansion_every_point=1, short_cut=0)
     base.update(kw)
     return default_params(**base)
 
@@ -122,7 +136,7 @@ class Oracle:
                   "orc_table_lookup", "orc_plan", "orc_get_path", "orc_get_expanded", "orc_footprint_table",
                   "orc_get_obstacles", "orc_in_range_count", "orc_num_obstacles", "orc_num_successors",
                   "orc_table_dims", "orc_build_table", "orc_rs_path", "orc_rs_sample", "orc_dubins",
-                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid", "orc_plan_r"):
+                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid", "orc_plan_r", "orc_shortcut"):
             getattr(L, f).argtypes = None
         self.params = params
         self.h = C.c_void_p(L.orc_create(C.byref(params)))
@@ -258,6 +272,12 @@ class Oracle:
                           C.c_size_t(exp_cap), C.byref(en))
         assert pn.value <= path_cap and en.value <= exp_cap
         return res[0], path[:pn.value].copy(), exp[:en.value].copy()
+
+    def shortcut(self, path):
+        path = np.ascontiguousarray(path, np.float32).reshape(-1, 3)
+        idx = np.zeros(len(path) + 2, np.uint32)
+        n = self.L.orc_shortcut(self.h, path.ctypes.data_as(C.c_void_p), C.c_uint32(len(path)), idx.ctypes.data_as(C.c_void_p))
+        return idx[:n].copy()
 
     def plan_many(self, starts, goals):
         starts = np.ascontiguousarray(starts, np.float32)

@@ -128,6 +128,8 @@ VARIANTS = {
     "goal_range_2": dict(goal_range=2.0),
     "tie_breaker_0": dict(tie_breaker=0.0),
     "penalties": dict(penalty_turning=1.3, penalty_reverse=2.0, penalty_change_of_direction=3.0),
+    "short_cut": dict(short_cut=1),
+    "short_cut_without_shots": dict(short_cut=1, analytical_expansion=0),
 }
 
 
@@ -139,3 +141,28 @@ def test_parameter_variants(name, oracle_built):
     res = h.plan_batch(S, G)
     assert res["nodes_expanded"].sum() > 2000
     assert _compare_threaded(o, h, S, G, res) == []
+
+
+def test_shortcut_paths_against_oracle(oracle_built):
+    """HybridAStar::ShortCut (src/hybrid_a_star.cpp:1076-1179) through hyas_shortcut_batch: traced search paths, random
+    walks that cut corners through obstacles, paths with nodes off the map and the degenerate lengths 0, 1 and 2."""
+    o, h, mp = _pair("map_maze", position_resolution=2, max_iterations=1500, analytical_expansion=0)
+    H, W = mp.shape
+    S, G = make_queries(h.collision, 48, 99, W, H)
+    res = h.plan_batch(S, G)
+    paths = [h.path(i) for i in range(len(S)) if res[i]["path_len"] >= 2]
+    assert len(paths) >= 20 and max(len(p) for p in paths) > 100
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 2, 3, 40, 400, 1000):
+        step = rng.normal(0, 0.6, (n, 2)).cumsum(0) + rng.uniform(10, 40, 2)
+        paths.append(np.concatenate([step, rng.uniform(0, 2 * math.pi, (n, 1))], 1).astype(np.float32))
+    free = h.collision(np.concatenate([p for p in paths if len(p)]))
+    assert 0.1 < free.mean() < 0.999
+    off = paths[-2].copy()
+    off[::7, 0] = -3.0  # nodes off the map
+    paths.append(off)
+    got = h.shortcut(paths)
+    for p, g in zip(paths, got):
+        want = o.shortcut(p)
+        assert np.array_equal(want, g), (len(p), want[:10], g[:10])
+    assert sum(len(g) for g in got) < sum(len(p) for p in paths)

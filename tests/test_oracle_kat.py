@@ -252,3 +252,20 @@ def test_plan_golden_regression(oracle_built):
         assert res.tobytes() == g[f"{name}/result"].tobytes(), name
         assert np.array_equal(exp, g[f"{name}/expanded"]), name
         assert path.tobytes() == g[f"{name}/path"].tobytes(), name
+
+
+def test_shortcut_on_simple_paths(oracle_built):
+    """ShortCut (src/hybrid_a_star.cpp:1076-1179) restated: on an empty map every node is reachable from the last one, so
+    the first and the last node remain; behind a wall the walk stops at the first node the segment test rejects."""
+    grid = np.zeros((30, 30), np.uint8)
+    o = orc.Oracle(orc.hot_path_params(position_resolution=1, short_cut=1))
+    o.set_costmap(grid, build_table=False)
+    path = np.stack([np.linspace(3, 25, 40), np.full(40, 10.0), np.zeros(40)], 1).astype(np.float32)
+    assert o.shortcut(path).tolist() == [0, 39]
+    assert o.shortcut(path[:2]).tolist() == [0, 1]
+    assert o.shortcut(path[:1]).tolist() == [0] and o.shortcut(path[:0]).tolist() == []
+    grid[5:20, 14] = 254  # a wall across the straight line; the path walks around its upper end
+    o.set_costmap(grid, build_table=False)
+    around = np.array([[8, 10, 0], [8, 16, 0], [8, 23, 0], [14, 24.5, 0], [20, 23, 0], [20, 16, 0], [20, 10, 0]], np.float32)
+    kept = o.shortcut(around).tolist()
+    assert kept[-1] == 6 and 0 < len(kept) < 7 and kept == sorted(kept)
