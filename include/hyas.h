@@ -31,6 +31,7 @@ extern "C" {
 
 #define HYAS_CURVE_DUBINS 0
 #define HYAS_CURVE_RS 1
+#define HYAS_CURVE_BEZIER 2 /* cubic Bezier heuristic + shot (src/cubic_bezier.cpp, include/bezier.h) */
 
 #define HYAS_MAX_SUCC 8 /* most successors one node can generate */
 
@@ -45,7 +46,7 @@ typedef struct hyas_params
     int32_t position_resolution;      /* 10 */
     int32_t headings;                 /* 72 */
     float cd_min_turning_radius;      /* 6: radius of the heuristic table */
-    int32_t curve_type;               /* 0 Dubins, 1 Reeds-Shepp */
+    int32_t curve_type;               /* 0 Dubins, 1 Reeds-Shepp, 2 cubic Bezier */
     float vehicle_width;              /* 1 */
     float vehicle_length;             /* 2 */
     float obstacle_detection_range;   /* 5 */

@@ -957,6 +957,154 @@ static int sample(const Path *path, float t, float q[3])
 // costmap_2d::Costmap2D is a ROS dependency absent from the reference tree;
 // restated: worldToMap rejects wx<origin or wy<origin, truncates
 // (w-origin)/resolution to int, accepts iff mx<size_x && my<size_y.
+// ====================================================================== cubic Bezier (curve_type 2)
+// Two different pieces of the reference are involved.  The heuristic table (src/lookup_table.cpp:226-277) uses the
+// third-party header include/bezier.h (Bezier::Bezier<3>::length, :744-768, Bernstein form with pow, :100-103,
+// :681-690); the analytic shot (src/hybrid_a_star.cpp:470-521) uses CubicBezier::CubicBezier (src/cubic_bezier.cpp),
+// Eigen matrix products of the geometry matrix, the basis matrix and a power vector.
+// Assumptions that no reference output pins (parity unpinned): std::pow / powf return the correctly rounded value for
+// the exponents 0..3 used here; Eigen is a 3.3 / 3.4 release, whose small fixed-size products take each coefficient as
+// (row . column).sum() with the unrolled scalar reduction, which halves the range: (p0 + p1) + (p2 + p3)
+// (Eigen/src/Core/ProductEvaluators.h product_evaluator::coeff, Eigen/src/Core/Redux.h redux_novec_unroller).
+namespace bez
+{
+// std::pow(double, k), k = 0..3, and its float overload
+static inline double pow_d(double u, unsigned k) { return k == 0 ? 1.0 : k == 1 ? u : k == 2 ? u * u : (u * u) * u; }
+static inline float pow_f(float t, unsigned k) { return (float)pow_d((double)t, k); }
+
+// include/bezier.h: Bezier<3> over Vec2 (float) control points
+struct Lib3
+{
+    float px[4], py[4];
+    // PolynomialPair::valueAt (:100-103): pow(1.0f - t, size_t) is the promoting (double) overload, pow(t, float) powf
+    static float poly(unsigned n, float t) { return (float)(pow_d((double)(1.0f - t), 3 - n) * (double)pow_f(t, n)); }
+    float valueAt(float t, int axis) const // :681-690
+    {
+        static const size_t binom[4] = {1, 3, 3, 1};
+        float sum = 0;
+        for (unsigned n = 0; n < 4; n++)
+            sum += binom[n] * poly(n, t) * (axis == 0 ? px[n] : py[n]);
+        return sum;
+    }
+    float length(size_t intervals = 100) const // :744-768
+    {
+        float length = 0.0f;
+        float t = 0.0f;
+        const float dt = 1.0f / (float)intervals;
+        float p1x = valueAt(t, 0), p1y = valueAt(t, 1);
+        for (size_t i = 0; i < intervals; i++)
+        {
+            float p2x = valueAt(t + dt, 0), p2y = valueAt(t + dt, 1);
+            float x = p2x - p1x, y = p2y - p1y;
+            length += m_sqrtf(x * x + y * y);
+            p1x = p2x, p1y = p2y;
+            t += dt;
+        }
+        return length;
+    }
+};
+// src/lookup_table.cpp:250-262: the curve from (0, 0, start angle 0) to (x, y, theta) and its length
+static float tableCost(float x, float y, float theta)
+{
+    const float start_angle = 0;
+    float dx = m_cosf(start_angle), dy = m_sinf(start_angle);
+    const float gx = x - 0.f, gy = y - 0.f;
+    float t = m_sqrtf(gx * gx + gy * gy) / 3; // (goal - start).length() / 3
+    Lib3 c;
+    c.px[0] = 0, c.py[0] = 0;
+    c.px[1] = 0 + dx * t, c.py[1] = 0 + dy * t;
+    dx = m_cosf(theta), dy = m_sinf(theta);
+    c.px[2] = x - dx * t, c.py[2] = y - dy * t;
+    c.px[3] = x, c.py[3] = y;
+    return c.length();
+}
+
+// src/cubic_bezier.cpp + include/cubic_bezier.h: Eigen::Matrix<float, 3, 4> geometry, 4 x 4 basis
+struct Cubic
+{
+    float G[3][4], GB[3][4];
+    Cubic(const float start[3], const float goal[3]) // :31-44, CalculateControlPoints :70-136 (use_random_ false)
+    {
+        static const float B[4][4] = {{1, -3, 3, -1}, {0, 3, -6, 3}, {0, 0, 3, -3}, {0, 0, 0, 1}};
+        float dir[3] = {m_cosf(start[2]), m_sinf(start[2]), 0};
+        const float tx = goal[0] - start[0], ty = goal[1] - start[1];
+        const float t = m_sqrtf(tx * tx + ty * ty) / 3;
+        float c1[3], c2[3];
+        for (int i = 0; i < 3; i++)
+            c1[i] = start[i] + dir[i] * t;
+        dir[0] = m_cosf(goal[2]), dir[1] = m_sinf(goal[2]);
+        for (int i = 0; i < 3; i++)
+            c2[i] = goal[i] - dir[i] * t;
+        for (int i = 0; i < 3; i++)
+            G[i][0] = start[i], G[i][1] = c1[i], G[i][2] = c2[i], G[i][3] = goal[i];
+        for (int i = 0; i < 3; i++) // geometrical_constraint_matrix_ * basis_matrix_
+            for (int j = 0; j < 4; j++)
+                GB[i][j] = (G[i][0] * B[0][j] + G[i][1] * B[1][j]) + (G[i][2] * B[2][j] + G[i][3] * B[3][j]);
+    }
+    void times(const float c[4], float out[3]) const
+    {
+        for (int i = 0; i < 3; i++)
+            out[i] = (GB[i][0] * c[0] + GB[i][1] * c[1]) + (GB[i][2] * c[2] + GB[i][3] * c[3]);
+    }
+    // :16-51; `i - 1 < 0` never holds for the unsigned i, so the i = 0 terms are 0 * pow(t, huge) = 0 for t <= 1
+    static void coef(float t, float c[4])
+    {
+        for (unsigned i = 0; i < 4; ++i)
+            c[i] = (float)pow_d((double)t, i);
+    }
+    static void coef1(float t, float c[4])
+    {
+        c[0] = 0;
+        for (unsigned i = 1; i < 4; ++i)
+            c[i] = (float)((double)i * pow_d((double)t, i - 1));
+    }
+    static void coef2(float t, float c[4])
+    {
+        c[0] = 0, c[1] = 0;
+        for (unsigned i = 2; i < 4; ++i)
+            c[i] = (float)((double)(i * (i - 1)) * pow_d((double)t, i - 2));
+    }
+    void GetValueAt(float t, float out[3]) const
+    {
+        float c[4];
+        coef(t, c);
+        times(c, out);
+    }
+    float GetAngleAt(float t) const // :158-165
+    {
+        float c[4], d[3];
+        coef1(t, c);
+        times(c, d);
+        return m_atan2f(d[1], d[0]);
+    }
+    float GetLength() const // :166-178
+    {
+        float length = 0;
+        for (unsigned i = 0; i < 100; ++i)
+        {
+            float a[3], b[3];
+            GetValueAt((float)((i + 1) / 100.0), a);
+            GetValueAt((float)(i / 100.0), b);
+            const float x = a[0] - b[0], y = a[1] - b[1];
+            length += m_sqrtf(x * x + y * y);
+        }
+        return length;
+    }
+    float GetCurvatureAt(float t) const // :224-241
+    {
+        float c[4], f[3], s[3];
+        coef1(t, c);
+        times(c, f);
+        coef2(t, c);
+        times(c, s);
+        const float fn = m_sqrtf(f[0] * f[0] + f[1] * f[1]);
+        if (fn != 0)
+            return (float)((double)m_fabsf(f[0] * s[1] - s[0] * f[1]) / pow_d((double)fn, 3));
+        return 100000;
+    }
+};
+} // namespace bez
+
 struct Costmap
 {
     uint32_t w = 0, h = 0;
@@ -1340,6 +1488,8 @@ struct Ctx
             double q0[3] = {0, 0, 0}, q1[3] = {x, y, theta};
             return (double)P.cd_min_turning_radius * reedsShepp(q0, q1, (double)P.cd_min_turning_radius).total;
         }
+        if (curve == HYAS_CURVE_BEZIER) // CalculateCubicBezierLookupV1, src/lookup_table.cpp:226-277
+            return bez::tableCost(x, y, theta);
         float q0[3] = {0, 0, 0}, q1[3] = {x, y, theta};
         db::Path p;
         if (db::init(q0, q1, P.cd_min_turning_radius, &p) != 0)
@@ -1406,7 +1556,7 @@ struct Ctx
     // src/lookup_table.cpp:56-96 (+ :113-122)
     float tableCost(float x, float y, float t) const
     {
-        float miss = (table_curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
+        float miss = (table_curve == HYAS_CURVE_RS) ? 100000000.f : (table_curve == HYAS_CURVE_BEZIER) ? 10000000.f : 1000000.f; // :59, :85, :101
         int index = CalculateNode3DIndex(x, y, RadToZeroTo2P(t));
         if (index >= 0 && (size_t)index < table.size() && table[index] == table[index])
             return table[index];
@@ -1626,6 +1776,35 @@ struct Ctx
                 if (path_vec)
                     path_vec->push_back(nd);
                 x = (float)((double)x + 0.2 * (double)resolution_);
+                px = nd.x, py = nd.y;
+                ++n;
+            }
+        }
+        else if (P.curve_type == HYAS_CURVE_BEZIER) // src/hybrid_a_star.cpp:470-521
+        {
+            const float vs[3] = {start.x, start.y, start.t}, vg[3] = {goal.x, goal.y, goal.t};
+            bez::Cubic cubic(vs, vg);
+            float length = cubic.GetLength();
+            if (length_out)
+                *length_out = length;
+            float x = 0;
+            while (x < length)
+            {
+                float v[3];
+                cubic.GetValueAt(x / length, v);
+                Node3D nd;
+                nd.x = v[0], nd.y = v[1];
+                float curvature = cubic.GetCurvatureAt(x / length);
+                nd.t = RadToZeroTo2P(cubic.GetAngleAt(x / length));
+                if (!IsTraversable(nd.x, nd.y, nd.t, true, px, py) || !(curvature <= 1 / P.min_turning_radius))
+                {
+                    if (path_vec)
+                        path_vec->clear();
+                    return false;
+                }
+                if (path_vec)
+                    path_vec->push_back(nd);
+                x = (float)((double)x + 0.1 * (double)resolution_);
                 px = nd.x, py = nd.y;
                 ++n;
             }
@@ -2220,6 +2399,16 @@ int orc_get_expanded(void *h, int32_t *idx, size_t cap)
 
 // ---- raw function access for known-answer tests --------------------------
 double orc_rs_distance(double rho, const double *q0, const double *q1) { return rho * orc::reedsShepp(q0, q1, rho).total; }
+// cubic Bezier: the table cost of one entry; and of one shot curve its length and at parameter t the value, heading and curvature
+float orc_bezier_table_cost(float x, float y, float theta) { return orc::bez::tableCost(x, y, theta); }
+float orc_bezier_eval(const float *start, const float *goal, float t, float *out5)
+{
+    orc::bez::Cubic c(start, goal);
+    float v[3];
+    c.GetValueAt(t, v);
+    out5[0] = v[0], out5[1] = v[1], out5[2] = v[2], out5[3] = c.GetAngleAt(t), out5[4] = c.GetCurvatureAt(t);
+    return c.GetLength();
+}
 int orc_rs_path(double rho, const double *q0, const double *q1, int *type, double *len5)
 {
     orc::RsPath p = orc::reedsShepp(q0, q1, rho);

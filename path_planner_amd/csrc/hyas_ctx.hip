@@ -581,8 +581,8 @@ static bool params_ok(const hyas_params *p, std::string &why)
         why = "piecewise_cubic_bezier_interpolation is not supported";
     else if (p->headings < 1 || p->headings > 720 || p->position_resolution < 1 || p->position_resolution > 64)
         why = "headings / position_resolution out of range";
-    else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS)
-        why = "curve_type must be 0 (Dubins) or 1 (Reeds-Shepp)";
+    else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS && p->curve_type != HYAS_CURVE_BEZIER)
+        why = "curve_type must be 0 (Dubins), 1 (Reeds-Shepp) or 2 (cubic Bezier)";
     else if (!(p->vehicle_width >= 0) || !(p->vehicle_length >= 0))
         why = "vehicle dimensions must not be negative";
     else if (!(p->min_turning_radius > 0) || !(p->cd_min_turning_radius > 0))
@@ -729,19 +729,26 @@ int hyas_table_dims(const hyas_ctx *c, int32_t *nx, int32_t *ny, int32_t *ns)
     return HYAS_OK;
 }
 
+static bool known_curve(int curve) { return curve == HYAS_CURVE_RS || curve == HYAS_CURVE_DUBINS || curve == HYAS_CURVE_BEZIER; }
+// the cost of a key the table does not hold: src/lookup_table.cpp:59 (Dubins), :85 (Reeds-Shepp), :101 (cubic Bezier)
+static float table_miss_of(int curve) { return curve == HYAS_CURVE_RS ? 100000000.f : curve == HYAS_CURVE_BEZIER ? 10000000.f : 1000000.f; }
+
 int hyas_table_build_dev(hyas_ctx *c, int curve, int k0, int k1, float *out_dev)
 {
     if (!c || !c->have_map)
         return HYAS_ESTATE;
     if (c->grid_only)
         return c->fail(HYAS_ESTATE, "the heuristic table needs hyas_set_costmap, not hyas_set_grid");
-    if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
-        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
+    if (!known_curve(curve))
+        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins), 1 (Reeds-Shepp) or 2 (cubic Bezier)");
     if (k0 < 0 || k1 > (int)c->tab_ts.size() || k0 > k1 || !out_dev)
         return c->fail(HYAS_EINVAL, "slice range outside the heading loop");
     HYAS_HIP(c, hipSetDevice(c->device));
     timer_begin(c);
-    if (curve == HYAS_CURVE_RS)
+    if (curve == HYAS_CURVE_BEZIER)
+        launch_table_bezier(c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts, (uint32_t)k0, (uint32_t)k1,
+                            out_dev, c->stream);
+    else if (curve == HYAS_CURVE_RS)
         launch_table_rs(c->d_tab_xs, (uint32_t)c->tab_xs.size(), c->d_tab_ys, (uint32_t)c->tab_ys.size(), c->d_tab_ts, (uint32_t)k0,
                         (uint32_t)k1, (double)c->P.cd_min_turning_radius, out_dev, c->stream);
     else
@@ -759,8 +766,8 @@ int hyas_table_install_dev(hyas_ctx *c, int curve, const float *raw_dev)
         return HYAS_ESTATE;
     if (c->grid_only || !c->d_table)
         return c->fail(HYAS_ESTATE, "the heuristic table needs hyas_set_costmap, not hyas_set_grid");
-    if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
-        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
+    if (!known_curve(curve))
+        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins), 1 (Reeds-Shepp) or 2 (cubic Bezier)");
     if (!raw_dev)
         return c->fail(HYAS_EINVAL, "null table");
     HYAS_HIP(c, hipSetDevice(c->device));
@@ -771,7 +778,7 @@ int hyas_table_install_dev(hyas_ctx *c, int curve, const float *raw_dev)
     hipError_t e = hipStreamSynchronize(c->stream);
     (void)hipFree(rank);
     HYAS_HIP(c, e);
-    c->dm.table_miss = (curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f; // src/lookup_table.cpp:59, :85
+    c->dm.table_miss = table_miss_of(curve);
     c->have_table = true;
     return HYAS_OK;
 }
@@ -782,8 +789,8 @@ int hyas_table_install_noalloc_dev(hyas_ctx *c, int curve, const float *raw_dev)
         return HYAS_ESTATE;
     if (c->grid_only || !c->d_table)
         return c->fail(HYAS_ESTATE, "the heuristic table needs hyas_set_costmap, not hyas_set_grid");
-    if (curve != HYAS_CURVE_RS && curve != HYAS_CURVE_DUBINS)
-        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins) or 1 (Reeds-Shepp)");
+    if (!known_curve(curve))
+        return c->fail(HYAS_EINVAL, "curve must be 0 (Dubins), 1 (Reeds-Shepp) or 2 (cubic Bezier)");
     if (!raw_dev)
         return c->fail(HYAS_EINVAL, "null table");
     if (c->table_size > HYAS_NOALLOC_MAX_KEYS)
@@ -802,7 +809,7 @@ int hyas_table_install_noalloc_dev(hyas_ctx *c, int curve, const float *raw_dev)
                          (uint32_t)c->tab_ts.size(), rank, c->d_table, c->table_size, c->stream);
     HYAS_HIP(c, hipGetLastError());
     HYAS_HIP(c, hipStreamSynchronize(c->stream));
-    c->dm.table_miss = (curve == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
+    c->dm.table_miss = table_miss_of(curve);
     c->have_table = true;
     return HYAS_OK;
 }
@@ -974,17 +981,25 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
             return rc;
         // Dubins shot: x after k additions of 0.2*resolution, float with the sum formed in double
         // (src/hybrid_a_star.cpp:396-424)
+        // and the cubic Bezier shot: the same with 0.1*resolution (src/hybrid_a_star.cpp:477-499), behind it in one buffer
         const size_t cap_db = cap / 2 + 16;
-        std::vector<float> seg_db(cap_db);
+        std::vector<float> seg_db(cap_db + cap);
         float x = 0.f;
         for (size_t k = 0; k < cap_db; ++k)
         {
             seg_db[k] = x;
             x = (float)((double)x + 0.2 * (double)m.res_f);
         }
+        x = 0.f;
+        for (size_t k = 0; k < cap; ++k)
+        {
+            seg_db[cap_db + k] = x;
+            x = (float)((double)x + 0.1 * (double)m.res_f);
+        }
         if ((rc = upload(c, c->d_seg_db, seg_db)) != HYAS_OK)
             return rc;
         m.seg_db = c->d_seg_db, m.seg_db_cap = (uint32_t)cap_db;
+        m.seg_bz = c->d_seg_db + cap_db, m.seg_bz_cap = (uint32_t)cap;
     }
 
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
@@ -993,7 +1008,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
         return rc;
     m.pose_off = c->d_pose_off, m.pose_idx = c->d_pose_idx, m.seg_off = c->d_seg_off, m.seg_idx = c->d_seg_idx;
     m.table = c->d_table, m.table_size = c->table_size;
-    m.table_miss = (c->P.curve_type == HYAS_CURVE_RS) ? 100000000.f : 1000000.f;
+    m.table_miss = table_miss_of(c->P.curve_type);
     c->have_map = true;
 
     if (build_table)

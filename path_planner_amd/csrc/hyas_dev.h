@@ -129,6 +129,9 @@ struct DevMap
     // Dubins shot: sample positions x_k of `x += 0.2 * res` in float (src/hybrid_a_star.cpp:396-424)
     const float *seg_db;
     uint32_t seg_db_cap;
+    // cubic Bezier shot: the same for `x += 0.1 * res` (src/hybrid_a_star.cpp:477-499)
+    const float *seg_bz;
+    uint32_t seg_bz_cap;
 };
 
 // ---------------------------------------------------------------- Utility::

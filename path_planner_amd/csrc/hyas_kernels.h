@@ -24,6 +24,8 @@ void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny,
                      float *out, hipStream_t s);
 void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,
                          float *out, hipStream_t s);
+void launch_table_bezier(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float *out,
+                         hipStream_t s);
 void launch_table_install(const DevMap &m, const float *raw, const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts,
                           uint32_t ns, uint32_t *rank, float *table, uint64_t table_size, hipStream_t s);
 void launch_table_lookup(const DevMap &m, const float *xyt, size_t n, float *cost, hipStream_t s);

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "hyas_kernels.h"
+#include "hyas_bezier.h"
 #include "hyas_dubins.h"
 #include "hyas_flood.h"
 #include "hyas_rs.h"
@@ -349,6 +350,45 @@ __global__ void __launch_bounds__(256) k_table_dubins(const float *__restrict__ 
         const float a[3] = {0, 0, 0}, b[3] = {xs[i], ys[j], ts[k]};
         db::Path p;
         out[e] = (db::init(a, b, rho, p) != 0) ? 1000000.f : db::length(p);
+    }
+}
+
+// The same for curve_type 2 (src/lookup_table.cpp:226-277): 100-interval polyline length of the cubic Bezier curve
+// from the origin, heading 0, to (xs[i], ys[j], ts[k]) with both inner control points a third of the chord away.
+// The 101 parameter values and their Bernstein weights are the same for every entry: the workgroup forms them once
+// in LDS, and every lane reads the same four weights per vertex (one broadcast read).
+__global__ void __launch_bounds__(256) k_table_bezier(const float *__restrict__ xs, uint32_t nx, const float *__restrict__ ys, uint32_t ny,
+                                                      const float *__restrict__ ts, uint32_t k0, uint32_t k1, float *__restrict__ out)
+{
+    __shared__ float4 s_w[HYAS_BZ_INTERVALS + 1];
+    if (threadIdx.x <= HYAS_BZ_INTERVALS)
+    {
+        float w[4];
+        bz::lib_weights(bz::lib_param(threadIdx.x), w);
+        s_w[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    const size_t total = (size_t)(k1 - k0) * ny * nx;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    {
+        uint32_t i = (uint32_t)(e % nx);
+        uint32_t j = (uint32_t)((e / nx) % ny);
+        uint32_t k = k0 + (uint32_t)(e / ((size_t)nx * ny));
+        float px[4], py[4];
+        bz::lib_control(xs[i], ys[j], ts[k], px, py);
+        float4 wv = s_w[0];
+        float w[4] = {wv.x, wv.y, wv.z, wv.w};
+        float ax = bz::lib_axis(w, px), ay = bz::lib_axis(w, py), length = 0.0f;
+        for (int v = 1; v <= HYAS_BZ_INTERVALS; ++v)
+        {
+            wv = s_w[v];
+            w[0] = wv.x, w[1] = wv.y, w[2] = wv.z, w[3] = wv.w;
+            const float bx = bz::lib_axis(w, px), by = bz::lib_axis(w, py);
+            const float dx = bx - ax, dy = by - ay;
+            length += hy_sqrtf(dx * dx + dy * dy);
+            ax = bx, ay = by;
+        }
+        out[e] = length;
     }
 }
 
@@ -745,7 +785,10 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     __shared__ float s_xyt[SHOT_BATCH + 1][3]; // [0] = the sample in front of this batch
     __shared__ volatile int s_hit;
     __shared__ unsigned int s_first, s_lists;
-    constexpr bool RS = CURVE == HYAS_CURVE_RS;
+    __shared__ bz::Curve s_bezier;          // cubic Bezier only
+    __shared__ float s_bezier_len;          //
+    __shared__ uint8_t s_sharp[SHOT_BATCH]; // sample's curvature is above 1 / min_turning_radius
+    constexpr bool RS = CURVE == HYAS_CURVE_RS, BZ = CURVE == HYAS_CURVE_BEZIER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StepIn node = in[slot];
     if (node.shoot == 0) // uniform across the workgroup
@@ -777,7 +820,33 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         sq.flag = (volatile HYAS_LDS int *)&s_hit, sq.flagged = true;
 
     // ---- phase 1 ------------------------------------------------------------
-    if (!RS)
+    if (BZ)
+    {
+        // Cubic Bezier (src/hybrid_a_star.cpp:470-476): the curve, then CubicBezier::GetLength: 101 polyline vertices
+        // and 100 segment norms side by side (staged in the sample buffer), their float sum in order on one lane
+        static_assert(SHOT_BATCH >= HYAS_BZ_INTERVALS + 1 && SHOT_THREADS >= HYAS_BZ_INTERVALS + 1, "polyline staged in the sample buffer");
+        const float a[3] = {node.x, node.y, node.t}, b[3] = {goal.x, goal.y, goal.t};
+        const bz::Curve c = bz::make(a, b); // every lane: a few dozen float operations, no broadcast needed
+        if (tid <= HYAS_BZ_INTERVALS)
+            bz::value(c, bz::powers(bz::length_param((unsigned)tid)), s_xyt[tid + 1][0], s_xyt[tid + 1][1]);
+        __syncthreads();
+        if (tid < HYAS_BZ_INTERVALS)
+        {
+            const float dx = s_xyt[tid + 2][0] - s_xyt[tid + 1][0], dy = s_xyt[tid + 2][1] - s_xyt[tid + 1][1];
+            s_xyt[tid + 1][2] = hy_sqrtf(dx * dx + dy * dy);
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            float len = 0;
+            for (int i = 0; i < HYAS_BZ_INTERVALS; ++i)
+                len += s_xyt[i + 1][2];
+            s_bezier = c, s_bezier_len = len;
+            s_hit = 0;
+            s_xyt[0][0] = node.x, s_xyt[0][1] = node.y, s_xyt[0][2] = node.t;
+        }
+    }
+    else if (!RS)
     {
         // Dubins: six float words, cheap next to the sample tests; one lane solves (src/hybrid_a_star.cpp:378-395)
         if (tid == 0)
@@ -895,6 +964,11 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         length = rho * path.total; // src/ReedsShepp.cpp:564
         nsamp = count_samples(seg_tab, seg_cap, length);
     }
+    else if (BZ)
+    {
+        length = (double)s_bezier_len;
+        nsamp = count_samples_db(m.seg_bz, m.seg_bz_cap, s_bezier_len); // x = 0; while (x < length) x += 0.1 * resolution
+    }
     else
     {
         dpath = s_dubins;
@@ -902,6 +976,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         length = (double)lf;
         nsamp = count_samples_db(m.seg_db, m.seg_db_cap, lf);
     }
+    const float sharpest = 1 / m.shot_rho; // src/hybrid_a_star.cpp:496
     bool collided = false;
     unsigned long long tested = 0;
     for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_BATCH)
@@ -915,6 +990,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
         {
             const uint32_t k = base + tid;
             float x = 0, y = 0, t = 0;
+            bool sharp = false;
             if (tid < SHOT_BATCH && k < nsamp)
             {
                 if (RS)
@@ -922,6 +998,16 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                     double s[3];
                     rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
                     x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+                }
+                else if (BZ)
+                {
+                    // src/hybrid_a_star.cpp:481-483: value, curvature and heading at x / length
+                    const bz::Powers pw = bz::powers(m.seg_bz[k] / s_bezier_len);
+                    float angle, curvature;
+                    bz::value(s_bezier, pw, x, y);
+                    bz::angle_curvature(s_bezier, pw, angle, curvature);
+                    t = rad_0_2pi(angle);
+                    sharp = !(curvature <= sharpest);
                 }
                 else
                 {
@@ -934,6 +1020,8 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                 __syncthreads(); // slot 0 has been refreshed before slot SHOT_BATCH is overwritten
             if (tid < SHOT_BATCH)
                 s_xyt[tid + 1][0] = x, s_xyt[tid + 1][1] = y, s_xyt[tid + 1][2] = t;
+            if (BZ && tid < SHOT_BATCH)
+                s_sharp[tid] = sharp ? 1 : 0;
         }
         __syncthreads();
         if (CLOCKS)
@@ -962,8 +1050,8 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
                 tt = clock64();
             if (k < nsamp && (STATS || s_hit == 0))
             {
-                if (pose_lane)
-                    hit = !(on_grid(m, x, y) && pose_free(m, sq, x, y, t));
+                if (pose_lane) // a Bezier sample also fails on its curvature (src/hybrid_a_star.cpp:496-510)
+                    hit = !(on_grid(m, x, y) && pose_free(m, sq, x, y, t)) || (BZ && s_sharp[j] != 0);
                 else
                     hit = !segment_free(m, sq, x, y, px, py);
                 tested += pose_lane;
@@ -1095,6 +1183,8 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
 {
     __shared__ rs::Path s_path;
     __shared__ db::Path s_dubins;
+    __shared__ float s_poly[HYAS_BZ_INTERVALS + 1][2], s_bezier_len; // cubic Bezier only
+    bz::Curve bezier = {};
     const int tid = threadIdx.x;
     const StepIn node = nodes[blockIdx.x];
     const hyas_goal goal = goals[node.query];
@@ -1112,6 +1202,24 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
                 s_path = p;
         }
     }
+    else if (CURVE == HYAS_CURVE_BEZIER)
+    {
+        const float a[3] = {node.x, node.y, node.t}, b[3] = {goal.x, goal.y, goal.t};
+        bezier = bz::make(a, b);
+        if (tid <= HYAS_BZ_INTERVALS)
+            bz::value(bezier, bz::powers(bz::length_param((unsigned)tid)), s_poly[tid][0], s_poly[tid][1]);
+        __syncthreads();
+        if (tid == 0) // CubicBezier::GetLength, src/cubic_bezier.cpp:166-178
+        {
+            float len = 0;
+            for (int i = 0; i < HYAS_BZ_INTERVALS; ++i)
+            {
+                const float dx = s_poly[i + 1][0] - s_poly[i][0], dy = s_poly[i + 1][1] - s_poly[i][1];
+                len += hy_sqrtf(dx * dx + dy * dy);
+            }
+            s_bezier_len = len;
+        }
+    }
     else if (tid == 0)
     {
         const float a[3] = {node.x, node.y, node.t}, b[3] = {goal.x, goal.y, goal.t};
@@ -1127,6 +1235,8 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
     uint32_t nsamp;
     if (CURVE == HYAS_CURVE_RS)
         nsamp = count_samples(seg_tab, seg_cap, rho * path.total);
+    else if (CURVE == HYAS_CURVE_BEZIER)
+        nsamp = count_samples_db(m.seg_bz, m.seg_bz_cap, s_bezier_len);
     else
         nsamp = count_samples_db(m.seg_db, m.seg_db_cap, db::length(dpath));
     if (!offsets)
@@ -1143,6 +1253,14 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
             double s[3];
             rs::interpolate(q0, path, seg_tab[k] / rho, rho, s);
             dst[3 * k] = (float)s[0], dst[3 * k + 1] = (float)s[1], dst[3 * k + 2] = rad_0_2pi((float)s[2]);
+        }
+        else if (CURVE == HYAS_CURVE_BEZIER)
+        {
+            const bz::Powers pw = bz::powers(m.seg_bz[k] / s_bezier_len);
+            float x, y, angle, curvature;
+            bz::value(bezier, pw, x, y);
+            bz::angle_curvature(bezier, pw, angle, curvature);
+            dst[3 * k] = x, dst[3 * k + 1] = y, dst[3 * k + 2] = rad_0_2pi(angle);
         }
         else
         {
@@ -1511,6 +1629,15 @@ void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t
     hipLaunchKernelGGL(k_table_dubins, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
 }
 
+void launch_table_bezier(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float *out,
+                         hipStream_t s)
+{
+    size_t total = (size_t)(k1 - k0) * ny * nx;
+    if (total == 0)
+        return;
+    hipLaunchKernelGGL(k_table_bezier, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, out);
+}
+
 void launch_table_install(const DevMap &m, const float *raw, const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts,
                           uint32_t ns, uint32_t *rank, float *table, uint64_t table_size, hipStream_t s)
 {
@@ -1548,13 +1675,17 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
     do                                                                                                                 \
     {                                                                                                                  \
         const int mode_ = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;                              \
-        const bool rs_ = m.curve_type == HYAS_CURVE_RS;                                                                \
+        const bool rs_ = m.curve_type == HYAS_CURVE_RS, bz_ = m.curve_type == HYAS_CURVE_BEZIER;                       \
         if (mode_ == 0 && rs_)                                                                                         \
             hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
         else if (mode_ == 1 && rs_)                                                                                    \
             hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
         else if (mode_ == 2 && rs_)                                                                                    \
             hipLaunchKernelGGL((KERNEL<2, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
+        else if (mode_ == 1 && bz_)                                                                                    \
+            hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_BEZIER>), grid, block, 0, stream, __VA_ARGS__);                   \
+        else if (bz_)                                                                                                  \
+            hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_BEZIER>), grid, block, 0, stream, __VA_ARGS__);                   \
         else if (mode_ == 1)                                                                                           \
             hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_DUBINS>), grid, block, 0, stream, __VA_ARGS__);                   \
         else                                                                                                           \
@@ -1592,6 +1723,8 @@ void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hy
         return;
     if (m.curve_type == HYAS_CURVE_RS)
         hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_RS>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
+    else if (m.curve_type == HYAS_CURVE_BEZIER)
+        hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_BEZIER>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
     else
         hipLaunchKernelGGL(k_shot_path<HYAS_CURVE_DUBINS>, dim3(n), dim3(256), 0, s, m, nodes, goals, seg_tab, seg_cap, offsets, out, n_out);
 }

@@ -10,6 +10,7 @@
 #include "../../path_planner_amd/csrc/hyas_prune.h"
 #include "../../path_planner_amd/csrc/hyas_rs.h"
 #include "../../path_planner_amd/csrc/hyas_flood.h"
+#include "../../path_planner_amd/csrc/hyas_bezier.h"
 #include <queue>
 
 using namespace hyas;
@@ -277,4 +278,39 @@ extern "C" void hg_flood(int w, int h, double res, double ox, double oy, float g
     }
     for (uint32_t c = 0; c < N; c++)
         out[c] = (ps[c] & 3) == 3 ? g[c] : -1.f;
+}
+
+// The cubic Bezier header run on the host, in the order the kernels use it.
+// Table entry (x, y, theta): weights of the 101 polyline vertices, then the running length.
+extern "C" float hg_bezier_table_cost(float x, float y, float theta)
+{
+    float px[4], py[4], w[4];
+    bz::lib_control(x, y, theta, px, py);
+    bz::lib_weights(bz::lib_param(0), w);
+    float ax = bz::lib_axis(w, px), ay = bz::lib_axis(w, py), length = 0.0f;
+    for (unsigned v = 1; v <= HYAS_BZ_INTERVALS; ++v)
+    {
+        bz::lib_weights(bz::lib_param(v), w);
+        const float bx = bz::lib_axis(w, px), by = bz::lib_axis(w, py), dx = bx - ax, dy = by - ay;
+        length += hy_sqrtf(dx * dx + dy * dy);
+        ax = bx, ay = by;
+    }
+    return length;
+}
+// Shot curve start -> goal: returns its length; out4 = {x, y, heading, curvature} at parameter t.
+extern "C" float hg_bezier_eval(const float *start, const float *goal, float t, float *out4)
+{
+    const bz::Curve c = bz::make(start, goal);
+    float vx[HYAS_BZ_INTERVALS + 1], vy[HYAS_BZ_INTERVALS + 1], len = 0;
+    for (unsigned i = 0; i <= HYAS_BZ_INTERVALS; ++i)
+        bz::value(c, bz::powers(bz::length_param(i)), vx[i], vy[i]);
+    for (unsigned i = 0; i < HYAS_BZ_INTERVALS; ++i)
+    {
+        const float dx = vx[i + 1] - vx[i], dy = vy[i + 1] - vy[i];
+        len += hy_sqrtf(dx * dx + dy * dy);
+    }
+    const bz::Powers pw = bz::powers(t);
+    bz::value(c, pw, out4[0], out4[1]);
+    bz::angle_curvature(c, pw, out4[2], out4[3]);
+    return len;
 }

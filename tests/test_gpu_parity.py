@@ -368,13 +368,68 @@ def test_dubins_plan(parking_dubins, maze_dubins_default):
         assert len(res) == n
 
 
+# ----------------------------------------------------------------- cubic Bezier (curve_type 2)
+@pytest.fixture(scope="module")
+def parking_bezier(oracle_built):
+    # curvature limit 1 / 2: shots connect inside the 60x30 map
+    return Pair("map_parking", position_resolution=2, curve_type=2, min_turning_radius=2.0, cd_min_turning_radius=2.0,
+                max_iterations=400)
+
+
+@pytest.fixture(scope="module")
+def maze_bezier(oracle_built):
+    return Pair("map_maze", position_resolution=2, curve_type=2, min_turning_radius=6.0, cd_min_turning_radius=6.0,
+                max_iterations=300)
+
+
+def test_bezier_table(parking_bezier):
+    p = parking_bezier
+    nx, ny, ns = p.h.table_dims()
+    assert (nx, ny, ns) == p.o.table_dims()
+    rng = np.random.default_rng(6)
+    q = np.stack([rng.uniform(0, p.W, 100000), rng.uniform(0, p.H, 100000), rng.uniform(-7, 7, 100000)], 1).astype(np.float32)
+    a, b = p.o.table_lookup(q), p.h.table_lookup(q)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    gx, gy = np.meshgrid(np.arange(nx) * 0.5, np.arange(ny) * 0.5, indexing="ij")
+    for t in (0.0, 1.0, 3.1, 6.2):
+        g = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, t)], 1).astype(np.float32)
+        a, b = p.o.table_lookup(g), p.h.table_lookup(g)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        hit = a < 1e7  # the origin key is never filled (src/lookup_table.cpp:243-247)
+        assert hit.mean() > 0.99
+        # a polyline inscribed in the curve is at least as long as the chord
+        chord = np.hypot(g[:, 0], g[:, 1])
+        assert (a[hit] >= chord[hit] * (1 - 1e-5)).all()
+
+
+def test_bezier_shot_and_expand(parking_bezier, maze_bezier):
+    for p, seed in ((parking_bezier, 83), (maze_bezier, 84)):
+        nodes, goals = _nodes(p, 1500, seed)
+        a, la = p.o.shot(nodes, goals)
+        b, lb = p.h.shot(nodes, goals)
+        assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+        sa, ca = p.o.expand(nodes, goals)
+        sb, cb = p.h.expand(nodes, goals)
+        assert np.array_equal(ca, cb)
+        assert sa.tobytes() == sb.tobytes()
+    assert parking_bezier.o.shot(*_nodes(parking_bezier, 1500, 83))[0].mean() > 0.02
+
+
+def test_bezier_plan(parking_bezier, maze_bezier):
+    for p, seed, n in ((parking_bezier, 93, 32), (maze_bezier, 94, 32)):
+        s, g = p.free_poses(n, seed), p.free_poses(n, seed + 1)
+        res = _plan_compare(p, s, g)
+        assert len(res) == n
+
+
 def test_abi_error_behaviour():
     """Call-order and argument errors come back as codes with a message; nothing crashes, nothing is computed."""
     import ctypes as C
 
     L = hl.load_library()
     # unsupported parameter sets are refused at creation
-    for kw in (dict(adaptive_step_size=1), dict(adaptive_steering_angle_and_step_size=1), dict(curve_type=2),
+    for kw in (dict(adaptive_step_size=1), dict(adaptive_steering_angle_and_step_size=1), dict(curve_type=3), dict(curve_type=-1),
                dict(vehicle_width=-1.0), dict(min_turning_radius=0.0), dict(number_of_successors=0), dict(headings=0)):
         p = hl.hot_path_params(**kw)
         assert L.hyas_create(C.byref(p), 0) is None, kw

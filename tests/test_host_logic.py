@@ -23,7 +23,8 @@ HG = ROOT / "tests" / "host_geom"
 def host_geom():
     so, src = HG / "libhost_geom.so", HG / "host_geom.cpp"
     deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h",
-            ROOT / "path_planner_amd/csrc/hyas_rs.h", ROOT / "path_planner_amd/csrc/hyas_flood.h"]
+            ROOT / "path_planner_amd/csrc/hyas_rs.h", ROOT / "path_planner_amd/csrc/hyas_flood.h",
+            ROOT / "path_planner_amd/csrc/hyas_bezier.h"]
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
                         "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
@@ -160,3 +161,34 @@ def test_make_plan_before_initialize_returns_false():
     assert pl.makePlan(PoseStamped.from_yaw(1, 1, 0), PoseStamped.from_yaw(2, 2, 0), plan) is False
     with pytest.raises(RuntimeError):
         pl.makePlanBatch(np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32))
+
+
+def test_bezier_header_equals_oracle(host_geom, oracle_built):
+    """The cubic Bezier header the kernels are built from (power-basis shot curve, Bernstein table curve), run on the
+    host, against the oracle's restatement of src/cubic_bezier.cpp and include/bezier.h: same bits."""
+    L = orc.Oracle(orc.hot_path_params()).L  # the portable-math build, as the kernels
+    L.orc_bezier_table_cost.restype = C.c_float
+    L.orc_bezier_table_cost.argtypes = [C.c_float] * 3
+    L.orc_bezier_eval.restype = C.c_float
+    L.orc_bezier_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    host_geom.hg_bezier_table_cost.restype = C.c_float
+    host_geom.hg_bezier_table_cost.argtypes = [C.c_float] * 3
+    host_geom.hg_bezier_eval.restype = C.c_float
+    host_geom.hg_bezier_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(12)
+    for _ in range(3000):
+        x, y, th = float(rng.integers(0, 600)) / 10, float(rng.integers(0, 300)) / 10, float(rng.uniform(0, 2 * math.pi))
+        a, b = L.orc_bezier_table_cost(x, y, th), host_geom.hg_bezier_table_cost(x, y, th)
+        assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (x, y, th, a, b)
+    vp = lambda v: v.ctypes.data_as(C.c_void_p)
+    for k in range(3000):
+        s = np.array([rng.uniform(0, 60), rng.uniform(0, 30), rng.uniform(0, 2 * math.pi)], np.float32)
+        g = np.array([rng.uniform(0, 60), rng.uniform(0, 30), rng.uniform(0, 2 * math.pi)], np.float32)
+        if k % 50 == 0:
+            g[:2] = s[:2]  # zero chord: all four control points coincide
+        t = np.float32(rng.uniform(0, 1)) if k % 7 else np.float32(0)
+        oa, ob = np.zeros(5, np.float32), np.zeros(4, np.float32)
+        la = L.orc_bezier_eval(vp(s), vp(g), t, vp(oa))
+        lb = host_geom.hg_bezier_eval(vp(s), vp(g), t, vp(ob))
+        assert np.float32(la).view(np.uint32) == np.float32(lb).view(np.uint32)
+        assert oa[[0, 1, 3, 4]].tobytes() == ob.tobytes(), (s, g, t, oa, ob)

@@ -269,3 +269,65 @@ def test_shortcut_on_simple_paths(oracle_built):
     around = np.array([[8, 10, 0], [8, 16, 0], [8, 23, 0], [14, 24.5, 0], [20, 23, 0], [20, 16, 0], [20, 10, 0]], np.float32)
     kept = o.shortcut(around).tolist()
     assert kept[-1] == 6 and 0 < len(kept) < 7 and kept == sorted(kept)
+
+
+def _bezier_polyline_length(start, goal, n=100):
+    """Float64 polyline length of the cubic Bezier curve both reference implementations describe: inner control points
+    a third of the chord from the end points along the end headings (src/cubic_bezier.cpp:113-124,
+    src/lookup_table.cpp:251-260)."""
+    s, g = np.asarray(start, float), np.asarray(goal, float)
+    third = np.hypot(*(g[:2] - s[:2])) / 3
+    c = np.array([s[:2], s[:2] + third * np.array([math.cos(s[2]), math.sin(s[2])]),
+                  g[:2] - third * np.array([math.cos(g[2]), math.sin(g[2])]), g[:2]])
+    t = np.linspace(0, 1, n + 1)[:, None]
+    pts = (1 - t) ** 3 * c[0] + 3 * (1 - t) ** 2 * t * c[1] + 3 * (1 - t) * t ** 2 * c[2] + t ** 3 * c[3]
+    return float(np.linalg.norm(np.diff(pts, axis=0), axis=1).sum())
+
+
+@pytest.mark.parametrize("libm", [False, True])
+def test_bezier_table_and_shot_against_float64(oracle_built, libm):
+    """curve_type 2.  The reference holds no output for its Bezier code (parity unpinned): the restatement is checked
+    against the curve's definition in float64, to float accuracy, and on cases whose answer is known in closed form."""
+    grid = np.zeros((40, 40), np.uint8)
+    o = orc.Oracle(orc.hot_path_params(position_resolution=1, curve_type=2, min_turning_radius=2.0, cd_min_turning_radius=2.0), libm=libm)
+    o.set_costmap(grid, build_table=True, nthreads=8)
+    # heuristic table: entry (x, y, k * 5 deg) is the 100-interval polyline length from the origin with heading 0
+    # (which heading of the build loop a heading bin holds: the loop's float accumulator, first value wins, :234-270)
+    delta, th, first_in_bin = np.float32(2 * math.pi / 72.0), np.float32(0), {}
+    while float(th) < 2 * math.pi:
+        first_in_bin.setdefault(int(th / delta), float(th))
+        th = np.float32(th + delta)
+    rng = np.random.default_rng(3)
+    bins = rng.choice(sorted(first_in_bin), 300)
+    xy = np.stack([rng.integers(1, 40, 300), rng.integers(0, 40, 300)], 1)
+    q = np.concatenate([xy, ((bins + 0.5) * float(delta))[:, None]], 1).astype(np.float32)
+    got = o.table_lookup(q)
+    want = np.array([_bezier_polyline_length((0, 0, 0), (x, y, first_in_bin[b])) for (x, y), b in zip(xy, bins)])
+    assert np.abs(got - want).max() <= 2e-5 * want.max()
+    # straight ahead: the curve is its chord
+    assert abs(o.table_lookup(np.array([[9, 0, 0]], np.float32))[0] - 9.0) < 1e-5
+    # the origin key is never written (src/lookup_table.cpp:243-247, :101)
+    assert o.table_lookup(np.array([[0.2, 0.3, 0.0]], np.float32))[0] == np.float32(10000000.0)
+    # analytic shot on an empty map: connects iff the curvature stays below 1 / min_turning_radius
+    nodes = np.zeros(4, orc.NODE_DT)
+    goals = np.zeros(4, orc.GOAL_DT)
+    cases = [((5, 5, 0), (25, 5, 0)),                       # straight: curvature 0
+             ((5, 5, 0), (20, 20, math.pi / 2)),            # a wide quarter turn
+             ((5, 5, 0), (6, 6, math.pi)),                  # a U-turn within one cell: far too sharp
+             ((5, 5, 0), (5, 5, 1.0))]                      # start == goal: zero length, no samples, no shot
+    for i, (s, g) in enumerate(cases):
+        nodes["x"][i], nodes["y"][i], nodes["t"][i] = s
+        goals["x"][i], goals["y"][i], goals["t"][i] = g
+    ok, ln = o.shot(nodes, goals)
+    assert ok.tolist() == [1, 1, 0, 0]
+    for i in range(3):
+        assert abs(ln[i] - _bezier_polyline_length(*cases[i])) <= 2e-5 * max(1.0, ln[i])
+    assert ln[3] == 0
+    # the same quarter turn with a radius the curve cannot keep
+    o2 = orc.Oracle(orc.hot_path_params(position_resolution=1, curve_type=2, min_turning_radius=30.0, cd_min_turning_radius=30.0), libm=libm)
+    o2.set_costmap(grid, build_table=False)
+    assert o2.shot(nodes[1:2], goals[1:2])[0].tolist() == [0]
+    # a planned path ends with the curve's samples, every 0.1 cell of arc parameter, and the goal
+    res, path, _ = o.plan((5, 5, 0), (25, 5, 0))
+    assert res["status"] == 2  # the analytic shot connected
+    assert len(path) > 10 and np.allclose(path[-1], (25, 5, 0)) and np.allclose(path[:, 1], 5, atol=1e-5)
