@@ -33,7 +33,8 @@ extern "C" {
 #define HYAS_CURVE_RS 1
 #define HYAS_CURVE_BEZIER 2 /* cubic Bezier heuristic + shot (src/cubic_bezier.cpp, include/bezier.h) */
 
-#define HYAS_MAX_SUCC 8 /* most successors one node can generate */
+#define HYAS_MAX_SUCC 8 /* most successors one node can generate (fixed steering set) */
+#define HYAS_ADAPTIVE_SLOTS 16 /* successor slots per node with adaptive_steering_angle_and_step_size; at most 15 are used */
 
 /* Planner parameters.  Field names, meaning and defaults follow
  * ParameterCollisionDetection and ParameterHybridAStar
@@ -53,8 +54,8 @@ typedef struct hyas_params
     int32_t map_boundary_obstacle;    /* 0 (only 0 is supported) */
     /* ParameterHybridAStar */
     int32_t number_of_successors;     /* 3 */
-    int32_t adaptive_steering_angle_and_step_size; /* must be 0 */
-    int32_t adaptive_step_size;       /* must be 0 */
+    int32_t adaptive_steering_angle_and_step_size; /* 0; wins over adaptive_step_size when both are set */
+    int32_t adaptive_step_size;       /* 1 */
     int32_t analytical_expansion_every_point;      /* 1 */
     int32_t analytical_expansion;     /* 1 */
     float penalty_turning;            /* 1.05 */
@@ -116,6 +117,7 @@ typedef struct hyas_succ
 #define HYAS_STATUS_SHOT 2      /* analytic expansion connected */
 #define HYAS_STATUS_MAX_ITER 3  /* max_iterations reached: partial path */
 #define HYAS_STATUS_BAD_POSE 4  /* start or goal rejected (makePlan pre-check) */
+#define HYAS_STATUS_OVERFLOW 5  /* adaptive steering: a node produced more candidates than HYAS_ADAPTIVE_SLOTS - 2 */
 
 typedef struct hyas_result
 {
@@ -188,6 +190,19 @@ int hyas_footprint_table(hyas_ctx *ctx, int32_t *out, size_t cap_entries);
  * hyas_num_successors() slots, compacted per node; count[i] = emitted. */
 int hyas_expand_batch(hyas_ctx *ctx, const hyas_node *preds, const hyas_goal *goals,
                       const float *twod_cost, size_t n, hyas_succ *out, uint8_t *count);
+/* The same with the start pose of the search each pair belongs to: with
+ * adaptive_steering_angle_and_step_size the steering towards the goal is
+ * weighted by the start-goal distance (CollisionDetection::FindStepSizeAndSteeringAngle,
+ * src/collisiondetection.cpp:1383-1401).  hyas_expand_batch refuses that mode.
+ * count[i] = 0xFF: node i produced more candidates than its slots hold. */
+int hyas_expand_batch_from(hyas_ctx *ctx, const hyas_node *preds, const hyas_goal *goals, const hyas_goal *starts,
+                           const float *twod_cost, size_t n, hyas_succ *out, uint8_t *count);
+/* replaces: the per-costmap maps of the adaptive modes, CollisionDetection::SetMinDistanceMap,
+ * SetDistanceAngleRangeMap, BuildObstacleDensityMap, BuildNormalizedObstacleDensityMap
+ * (src/collisiondetection.cpp:387-500, :1013-1151, :1403-1447), built inside hyas_set_costmap; this call reads
+ * one grid key back: minimum obstacle distance, normalised density and up to cap {distance, start, width} angle
+ * ranges as FindFreeAngleRangeAndObstacleAngleRange (:688-725) returns them.  Returns the number of ranges. */
+int hyas_adaptive_cell(hyas_ctx *ctx, uint32_t key, float *min_distance, float *density, float *ranges3, size_t cap);
 int hyas_num_successors(const hyas_ctx *ctx);
 
 /* replaces: HybridAStar::AnalyticExpansions src/hybrid_a_star.cpp:371-534.

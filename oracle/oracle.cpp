@@ -384,6 +384,187 @@ static Polygon CombinePolygon(const Polygon &p1, const Polygon &p2)
     return out;
 }
 
+// ------------------------------------------------------------------ angle ranges (adaptive step size / steering)
+// Utility::AngleRange = std::pair<float, float>{start, range}, both in rad (include/utility.h:28)
+typedef std::pair<float, float> AngleRange;
+// src/utility.cpp:1186-1191
+static float ConvertRadToDeg(float rad) { return (float)((double)(rad / 2) / kPi * 360); }
+// src/utility.cpp:1789-1792
+static float GetAngleRangeEnd(const AngleRange &ar) { return ar.first + ar.second; }
+// src/utility.cpp:1836-1849
+static float GetAngleDistance(float angle1, float angle2)
+{
+    float out = angle2 - angle1;
+    if ((double)out >= kPi || (double)out <= -kPi)
+        out = RadNormalization(out);
+    return out;
+}
+// src/utility.cpp:1831-1834
+static float GetAngleDistance(float angle, const AngleRange &ar)
+{
+    return std::min(m_fabsf(GetAngleDistance(angle, ar.first)), m_fabsf(GetAngleDistance(angle, GetAngleRangeEnd(ar))));
+}
+// src/utility.cpp:1812-1823
+static bool IsEqual(float a1, float a2) { return m_fabsf(GetAngleDistance(a1, a2)) < ConvertDegToRad(0.01f); }
+// src/utility.cpp:1824-1829
+static bool IsEqual(const AngleRange &ar1, const AngleRange &ar2)
+{
+    return IsEqual(ar1.first, ar2.first) && IsEqual(GetAngleRangeEnd(ar1), GetAngleRangeEnd(ar2));
+}
+// src/utility.cpp:1298-1330
+static bool IsAngleRangeInclude(const AngleRange &angle_range, float angle)
+{
+    float angle_range_end = GetAngleRangeEnd(angle_range);
+    if (IsEqual(angle, angle_range.first))
+        return true;
+    if (IsEqual(angle, angle_range_end))
+        return true;
+    if ((RadToZeroTo2P(angle) >= RadToZeroTo2P(angle_range.first)) && (RadToZeroTo2P(angle) <= RadToZeroTo2P(angle_range_end)))
+        return true;
+    if ((RadNormalization(angle) >= RadNormalization(angle_range.first)) && (RadNormalization(angle) <= RadNormalization(angle_range_end)))
+        return true;
+    return false;
+}
+// src/utility.cpp:798-827
+static bool IsAngleRangeInclude(const AngleRange &angle_range_1, const AngleRange &angle_range_2)
+{
+    if (angle_range_2.second == 0)
+        return IsAngleRangeInclude(angle_range_1, angle_range_2.first);
+    if (IsEqual(angle_range_1.first, GetAngleRangeEnd(angle_range_2)) && IsEqual(GetAngleRangeEnd(angle_range_1), angle_range_2.first))
+        return false;
+    float angle_range_2_start = angle_range_2.first;
+    float angle_range_2_end = GetAngleRangeEnd(angle_range_2);
+    if (IsAngleRangeInclude(angle_range_1, angle_range_2_start) && IsAngleRangeInclude(angle_range_1, angle_range_2_end) &&
+        (angle_range_1.second > angle_range_2.second))
+        return true;
+    return false;
+}
+// src/utility.cpp:771-796
+static bool IsOverlap(const AngleRange &angle_range_1, const AngleRange &angle_range_2)
+{
+    float angle_range_1_start = angle_range_1.first;
+    float angle_range_1_end = GetAngleRangeEnd(angle_range_1);
+    float angle_range_2_start = angle_range_2.first;
+    float angle_range_2_end = GetAngleRangeEnd(angle_range_2);
+    if (IsAngleRangeInclude(angle_range_1, angle_range_2) || IsAngleRangeInclude(angle_range_2, angle_range_1))
+        return false;
+    else if ((IsAngleRangeInclude(angle_range_1, angle_range_2_start) && !IsAngleRangeInclude(angle_range_1, angle_range_2_end)) ||
+             (!IsAngleRangeInclude(angle_range_1, angle_range_2_start) && IsAngleRangeInclude(angle_range_1, angle_range_2_end)) ||
+             (IsAngleRangeInclude(angle_range_2, angle_range_1_start) && !IsAngleRangeInclude(angle_range_2, angle_range_1_end)) ||
+             (!IsAngleRangeInclude(angle_range_2, angle_range_1_start) && IsAngleRangeInclude(angle_range_2, angle_range_1_end)))
+        return true;
+    return false;
+}
+// src/utility.cpp:1465-1492
+static std::vector<AngleRange> FindAngleRange(float a1, float a2)
+{
+    std::vector<AngleRange> out;
+    float temp1 = RadToZeroTo2P(a1), temp2 = RadToZeroTo2P(a2), range;
+    if (IsEqual(temp1, temp2))
+    {
+        out.emplace_back(AngleRange(temp1, 0));
+        return out;
+    }
+    range = temp2 - temp1;
+    out.emplace_back(AngleRange(temp1, range));
+    if ((double)range > kPi)
+    {
+        out[0].second = (float)kPi;
+        out.emplace_back(AngleRange(RadToZeroTo2P((float)((double)temp1 + kPi)), (float)((double)range - kPi)));
+    }
+    return out;
+}
+// src/utility.cpp:1737-1782
+static AngleRange FindCommonAngleRange(const AngleRange &ar1, const AngleRange &ar2)
+{
+    AngleRange out;
+    if (IsAngleRangeInclude(ar1, ar2))
+        return ar2;
+    if (IsAngleRangeInclude(ar2, ar1))
+        return ar1;
+    if (IsEqual(ar1, ar2))
+        return ar1;
+    if (IsOverlap(ar1, ar2))
+    {
+        float ar1_end = GetAngleRangeEnd(ar1);
+        float ar2_end = GetAngleRangeEnd(ar2);
+        if (IsAngleRangeInclude(ar1, ar2.first) && IsAngleRangeInclude(ar2, ar1_end))
+            return FindAngleRange(ar2.first, ar1_end)[0];
+        if (IsAngleRangeInclude(ar1, ar2_end) && IsAngleRangeInclude(ar2, ar1.first))
+            return FindAngleRange(ar1.first, ar2_end)[0];
+    }
+    out.first = -1;
+    out.second = -1;
+    return out;
+}
+// src/utility.cpp:1928-1948
+static bool DuplicateCheck(const std::vector<std::pair<float, float>> &vector, const std::pair<float, float> &element, bool flag)
+{
+    for (const auto &pair : vector)
+        if (m_fabsf(pair.second - element.second) < ConvertDegToRad(1))
+        {
+            if (flag)
+            {
+                if ((double)m_fabsf(pair.first - element.first) < 1e-2)
+                    return true;
+            }
+            else
+                return true;
+        }
+    return false;
+}
+// ComputationalGeometry::Segment (src/computational_geometry.cpp:12-62)
+struct CgSegment
+{
+    V2 start_, end_;
+    CgSegment(V2 a, V2 b) : start_(a), end_(b) {}
+    CgSegment(V2 start, float radius, float rad) : start_(start) // :12-18
+    {
+        V2 rotation{m_cosf(rad), m_sinf(rad)};
+        end_ = V2{start_.x + radius * rotation.x, start_.y + radius * rotation.y};
+    }
+    bool IsIntersect(const CgSegment &o) const // :20-45
+    {
+        if ((start_.x == end_.x && end_.x == o.start_.x && o.start_.x == o.end_.x) ||
+            (start_.y == end_.y && end_.y == o.start_.y && o.start_.y == o.end_.y))
+            return false;
+        if (std::max(o.start_.x, o.end_.x) < std::min(start_.x, end_.x) || std::max(o.start_.y, o.end_.y) < std::min(start_.y, end_.y) ||
+            std::max(start_.x, end_.x) < std::min(o.start_.x, o.end_.x) || std::max(start_.y, end_.y) < std::min(o.start_.y, o.end_.y))
+            return false;
+        return CrossProduct(start_ - o.start_, o.end_ - o.start_) * CrossProduct(end_ - o.start_, o.end_ - o.start_) <= 0 &&
+               CrossProduct(o.start_ - end_, start_ - end_) * CrossProduct(o.end_ - end_, start_ - end_) <= 0;
+    }
+    V2 FindIntersectionPoint(const CgSegment &o) const // :46-62
+    {
+        if (!IsIntersect(o))
+            return V2{10000, 10000};
+        V2 dir_1 = end_ - start_, dir_2 = o.end_ - o.start_;
+        float t = CrossProduct(o.start_ - start_, dir_2) / CrossProduct(dir_1, dir_2);
+        return V2{start_.x + t * dir_1.x, start_.y + t * dir_1.y};
+    }
+};
+// src/utility.cpp:1072-1109
+static float GetDistanceFromPolygonToPointAtAngle(const Polygon &polygon, V2 point, float angle)
+{
+    float out = -1;
+    CgSegment segment(point, 10000, angle);
+    if (IsOnPolygon(polygon, point))
+        return 0;
+    if (!IsSegmentIntersectWithPolygon(polygon, segment.start_, segment.end_))
+        return out;
+    for (size_t index = 0; index + 1 < polygon.size(); ++index)
+    {
+        CgSegment segment_on_polygon(polygon[index], polygon[index + 1]);
+        if (segment.IsIntersect(segment_on_polygon))
+        {
+            float distance = norm(segment.FindIntersectionPoint(segment_on_polygon) - point);
+            if (out > distance || out < 0)
+                out = distance;
+        }
+    }
+    return out;
+}
+
 // src/utility.cpp:2073-2089
 static std::vector<float> FormSteeringAngleVec(float steering_angle, int number_of_successors)
 {
@@ -1160,6 +1341,9 @@ struct Ctx
     std::vector<int8_t> grid;              // nav_msgs::OccupancyGrid data
     std::vector<Polygon> obstacle_vec_;
     std::unordered_map<uint32_t, std::vector<Polygon>> in_range_obstacle_map_;
+    // adaptive step size / steering (include/collisiondetection.h:328-345)
+    std::unordered_map<uint32_t, float> min_distance_map_, in_range_obstacle_density_map_, normalized_obstacle_density_map_;
+    std::unordered_map<uint32_t, std::vector<std::pair<float, AngleRange>>> distance_angle_range_map_;
     // LookupTable: keyed dense store; NaN = key never emplaced
     std::vector<float> table;
     int table_curve = -1;
@@ -1241,6 +1425,369 @@ struct Ctx
             }
             x = x + resolution_;
         }
+    }
+
+    // ------------------------------------- adaptive step size / steering: maps built once per costmap
+    // src/collisiondetection.cpp:1403-1447
+    void SetMinDistanceMap()
+    {
+        min_distance_map_.clear();
+        float x_limit = origin_x_ + cm.w * resolution_;
+        float y_limit = origin_y_ + cm.h * resolution_;
+        float min_distance = 1000, distance = 0;
+        for (float x = origin_x_; x < x_limit;)
+        {
+            for (float y = origin_y_; y < y_limit;)
+            {
+                uint32_t current_point_index = GetNode3DIndexOnGridMap(x, y);
+                auto it = in_range_obstacle_map_.find(current_point_index);
+                if (it != in_range_obstacle_map_.end())
+                    for (const Polygon &obstacle : it->second)
+                    {
+                        distance = GetDistanceFromPolygonToPoint(obstacle, V2{x, y});
+                        if (min_distance > distance)
+                            min_distance = distance;
+                    }
+                min_distance_map_.emplace(current_point_index, min_distance);
+                y = y + resolution_;
+                min_distance = 1000;
+            }
+            x = x + resolution_;
+        }
+    }
+    // src/collisiondetection.cpp:973-1011
+    float FindNoCollisionDistance(float nx, float ny, float radius, float angle)
+    {
+        float out = radius;
+        uint32_t current_index = GetNode3DIndexOnGridMap(nx, ny);
+        auto it = in_range_obstacle_map_.find(current_index);
+        if (it != in_range_obstacle_map_.end())
+            for (const Polygon &in_range_polygon : it->second)
+            {
+                float temp = GetDistanceFromPolygonToPointAtAngle(in_range_polygon, V2{nx, ny}, angle);
+                if (temp < 0)
+                    continue;
+                if (out > temp)
+                    out = temp;
+            }
+        return out;
+    }
+    // src/collisiondetection.cpp:940-970 with consider_steering_angle == false: {angle, free distance} every degree
+    std::vector<std::pair<float, float>> SweepDistanceAndAngle(float nx, float ny, float radius)
+    {
+        std::vector<std::pair<float, float>> out;
+        AngleRange steering_angle_range(0, ConvertDegToRad(360));
+        float angle = steering_angle_range.first;
+        for (; angle <= steering_angle_range.first + steering_angle_range.second; angle = angle + ConvertDegToRad(1))
+            out.emplace_back(angle, FindNoCollisionDistance(nx, ny, radius, angle));
+        return out;
+    }
+    // src/collisiondetection.cpp:387-500
+    void SetDistanceAngleRangeMap()
+    {
+        distance_angle_range_map_.clear();
+        const float obstacle_detection_range_ = P.obstacle_detection_range;
+        std::vector<std::pair<float, AngleRange>> distance_angle_range_vec;
+        float x_limit = origin_x_ + cm.w * resolution_;
+        float y_limit = origin_y_ + cm.h * resolution_;
+        for (float x = origin_x_; x < x_limit;)
+        {
+            for (float y = origin_y_; y < y_limit;)
+            {
+                distance_angle_range_vec.clear();
+                uint32_t current_point_index = GetNode3DIndexOnGridMap(x, y);
+                std::vector<std::pair<float, float>> angle_distance_vec = SweepDistanceAndAngle(x, y, obstacle_detection_range_);
+                float range_start = -1, range_range = -1, min_distance = 0;
+                auto md = min_distance_map_.find(current_point_index);
+                if (md != min_distance_map_.end())
+                    min_distance = md->second;
+                bool free_angle_range_flag = false, obstacle_angle_range_flag = false;
+                for (const auto &pair : angle_distance_vec)
+                {
+                    if (pair.second == obstacle_detection_range_)
+                    {
+                        if (obstacle_angle_range_flag)
+                        {
+                            obstacle_angle_range_flag = false;
+                            free_angle_range_flag = true;
+                            range_range = pair.first - range_start;
+                            if (range_start != -1 && range_range != -1)
+                            {
+                                distance_angle_range_vec.emplace_back(min_distance, AngleRange(range_start, range_range));
+                                range_start = pair.first;
+                            }
+                            else
+                                range_start = pair.first;
+                        }
+                        if (!free_angle_range_flag)
+                        {
+                            free_angle_range_flag = true;
+                            obstacle_angle_range_flag = false;
+                            range_start = pair.first;
+                        }
+                    }
+                    else
+                    {
+                        if (free_angle_range_flag)
+                        {
+                            free_angle_range_flag = false;
+                            obstacle_angle_range_flag = true;
+                            range_range = pair.first - range_start;
+                            if (range_start != -1 && range_range != -1)
+                            {
+                                distance_angle_range_vec.emplace_back(obstacle_detection_range_, AngleRange(range_start, range_range));
+                                range_start = pair.first;
+                            }
+                            else
+                                range_start = pair.first;
+                        }
+                        if (!obstacle_angle_range_flag)
+                        {
+                            free_angle_range_flag = false;
+                            obstacle_angle_range_flag = true;
+                            range_start = pair.first;
+                        }
+                    }
+                    if (pair.first == angle_distance_vec.back().first)
+                    {
+                        range_range = pair.first - range_start;
+                        if (range_start != -1 && range_range != -1 && range_range != 0)
+                            distance_angle_range_vec.emplace_back(min_distance, AngleRange(range_start, range_range));
+                    }
+                }
+                distance_angle_range_map_.emplace(current_point_index, distance_angle_range_vec);
+                y = y + resolution_;
+            }
+            x = x + resolution_;
+        }
+    }
+    // src/collisiondetection.cpp:1013-1103, consider_steering_angle_range_for_obstacle_density == false
+    void BuildObstacleDensityMap()
+    {
+        in_range_obstacle_density_map_.clear();
+        float x_limit = origin_x_ + cm.w * resolution_;
+        float y_limit = origin_y_ + cm.h * resolution_;
+        for (float x = origin_x_; x < x_limit;)
+        {
+            for (float y = origin_y_; y < y_limit;)
+            {
+                uint32_t current_point_index = GetNode3DIndexOnGridMap(x, y);
+                auto it = in_range_obstacle_map_.find(current_point_index);
+                if (it != in_range_obstacle_map_.end())
+                    in_range_obstacle_density_map_.emplace(current_point_index, (float)it->second.size());
+                y = y + resolution_;
+            }
+            x = x + resolution_;
+        }
+    }
+    // src/collisiondetection.cpp:1110-1151
+    void BuildNormalizedObstacleDensityMap()
+    {
+        normalized_obstacle_density_map_.clear();
+        float normalized_obstacle_density, delta = 0.01;
+        float max_density = 0, min_density = 1000000;
+        for (const auto &element : in_range_obstacle_density_map_)
+        {
+            if (element.second > max_density)
+                max_density = element.second;
+            if (element.second < min_density)
+                min_density = element.second;
+        }
+        for (const auto &element : in_range_obstacle_density_map_)
+        {
+            normalized_obstacle_density = (element.second - min_density) / (max_density - min_density + delta);
+            normalized_obstacle_density_map_.emplace(element.first, normalized_obstacle_density);
+        }
+    }
+    // the hybrid_astar part of UpdateGrid, src/collisiondetection.cpp:39-46
+    void buildAdaptiveMaps()
+    {
+        SetMinDistanceMap();
+        SetDistanceAngleRangeMap();
+        BuildObstacleDensityMap();
+        BuildNormalizedObstacleDensityMap();
+    }
+
+    // ------------------------------------- adaptive step size / steering: per node
+    // src/collisiondetection.cpp:1153-1177 (index by grid cell: the default)
+    float GetNormalizedObstacleDensity(const Node3D &node3d)
+    {
+        float obstacle_density = 0;
+        auto it = normalized_obstacle_density_map_.find(GetNode3DIndexOnGridMap(node3d.x, node3d.y));
+        if (it != normalized_obstacle_density_map_.end())
+            obstacle_density = it->second;
+        return obstacle_density;
+    }
+    // src/collisiondetection.cpp:1206-1221
+    static float GetStepSizeWeight(float normalized_obstacle_density) { return (float)(-0.8 * (double)normalized_obstacle_density + 0.9); }
+    // src/collisiondetection.cpp:1364-1381
+    static float LimitSteeringAngle(float steering_angle, float steering_angle_limit)
+    {
+        if (steering_angle > steering_angle_limit)
+            return steering_angle_limit;
+        else if (steering_angle < -steering_angle_limit)
+            return -steering_angle_limit;
+        return ConvertDegToRad(m_roundf(ConvertRadToDeg(steering_angle) * 10) / 10);
+    }
+    // src/collisiondetection.cpp:688-725
+    std::vector<std::pair<float, AngleRange>> FindFreeAngleRangeAndObstacleAngleRange(const Node3D &node3d)
+    {
+        std::vector<std::pair<float, AngleRange>> out;
+        AngleRange steering_angle_range(0, ConvertDegToRad(359.9999f));
+        auto it = distance_angle_range_map_.find(GetNode3DIndexOnGridMap(node3d.x, node3d.y));
+        if (it != distance_angle_range_map_.end())
+            for (const auto &pair : it->second)
+            {
+                AngleRange common = FindCommonAngleRange(pair.second, steering_angle_range);
+                if (common.first != -1 && common.second != -1)
+                    out.emplace_back(pair.first, common);
+            }
+        return out;
+    }
+    // src/collisiondetection.cpp:1449-1484
+    float FindStepSize(const Node3D &pred, float steering_angle, const Node3D &goal, float fixed_step_size)
+    {
+        float step_size = 0, min_distance_to_obstacle = P.obstacle_detection_range;
+        float distance_to_goal = GetDistance(pred, goal);
+        std::vector<std::pair<float, AngleRange>> step_size_angle_range_vec = FindFreeAngleRangeAndObstacleAngleRange(pred);
+        float final_orientation = RadNormalization(pred.t + steering_angle);
+        for (const auto &element : step_size_angle_range_vec)
+            if (IsAngleRangeInclude(element.second, final_orientation))
+            {
+                min_distance_to_obstacle = element.first;
+                break;
+            }
+        float weight_step_size = GetStepSizeWeight(GetNormalizedObstacleDensity(pred));
+        step_size = weight_step_size * min_distance_to_obstacle;
+        if (step_size < fixed_step_size)
+            step_size = fixed_step_size;
+        if (step_size > distance_to_goal)
+            step_size = distance_to_goal;
+        return step_size;
+    }
+    // src/collisiondetection.cpp:1263-1291
+    std::pair<float, float> AddOneMoreStepSizeAndSteeringAngle(float angle_to_goal, float step_size, const Node3D &pred, const Node3D &goal)
+    {
+        float distance_to_goal = GetDistance(pred, goal);
+        float new_step_size = (distance_to_goal < step_size) ? distance_to_goal : step_size;
+        return std::pair<float, float>(new_step_size, LimitSteeringAngle(angle_to_goal, ConvertDegToRad(30)));
+    }
+    // src/collisiondetection.cpp:1293-1362.  Without a free range among the node's own ranges the reference fills
+    // two shadowing locals and compares the untouched outer pair (10000 > 10000): angle1 is returned.
+    float IsCloseToFreeAngleRange(const std::vector<std::pair<float, AngleRange>> &available_angle_range_vec, float angle1, float angle2)
+    {
+        const float obstacle_detection_range_ = P.obstacle_detection_range;
+        bool free_angle_range_in_steering_angle = false;
+        float distance_angle1 = 10000, distance_angle2 = 10000;
+        for (const auto &pair : available_angle_range_vec)
+            if (pair.first == obstacle_detection_range_)
+                free_angle_range_in_steering_angle = true;
+        if (free_angle_range_in_steering_angle)
+            for (const auto &pair : available_angle_range_vec)
+                if (pair.first == obstacle_detection_range_)
+                {
+                    float temp1 = GetAngleDistance(angle1, pair.second), temp2 = GetAngleDistance(angle2, pair.second);
+                    distance_angle1 = std::min(temp1, distance_angle1);
+                    distance_angle2 = std::min(temp2, distance_angle2);
+                }
+        if (distance_angle1 > distance_angle2)
+            return angle2;
+        return angle1;
+    }
+    // src/collisiondetection.cpp:728-938
+    std::vector<std::pair<float, float>> SelectStepSizeAndSteeringAngle(const std::vector<std::pair<float, AngleRange>> &available_angle_range_vec,
+                                                                        const Node3D &pred, const Node3D &goal, int number_of_successor,
+                                                                        float fixed_step_size, float distance_start_to_goal)
+    {
+        const float obstacle_detection_range_ = P.obstacle_detection_range;
+        std::vector<std::pair<float, float>> out;
+        float steering_angle, distance_to_goal = GetDistance(pred, goal);
+        float angle_to_goal, orientation_diff, steering_angle_toward_goal = 0;
+        if (P.add_one_more_successor)
+        {
+            float weighting = distance_to_goal / distance_start_to_goal;
+            angle_to_goal = GetAngle(pred, goal);
+            orientation_diff = -RadNormalization(pred.t - goal.t);
+            steering_angle_toward_goal = -RadNormalization(weighting * angle_to_goal + (1 - weighting) * orientation_diff);
+        }
+        auto push = [&](const std::pair<float, float> &temp) {
+            if (!DuplicateCheck(out, temp, false))
+                out.emplace_back(temp);
+        };
+        for (const auto &pair : available_angle_range_vec)
+        {
+            if (pair.second.second == 0)
+            {
+                steering_angle = RadNormalization(pair.second.first - pred.t);
+                steering_angle = LimitSteeringAngle(steering_angle, ConvertDegToRad(30));
+                push(std::pair<float, float>(pair.first, steering_angle));
+                continue;
+            }
+            if (pair.first == obstacle_detection_range_)
+            {
+                if (P.add_one_more_successor)
+                    push(AddOneMoreStepSizeAndSteeringAngle(steering_angle_toward_goal,
+                                                            FindStepSize(pred, steering_angle_toward_goal, goal, fixed_step_size), pred, goal));
+                if (P.fixed_number_of_steering_angle_in_free_angle_range)
+                {
+                    steering_angle = RadNormalization((float)((double)pair.second.first + 0.5 * (double)pair.second.second - (double)pred.t));
+                    steering_angle = LimitSteeringAngle(steering_angle, ConvertDegToRad(30));
+                    push(std::pair<float, float>(FindStepSize(pred, steering_angle, goal, fixed_step_size), steering_angle));
+                }
+                else
+                {
+                    if (pair.second.second < ConvertDegToRad(3))
+                    {
+                        steering_angle = RadNormalization((float)((double)pair.second.first + (double)pair.second.second * 0.5 - (double)pred.t));
+                        steering_angle = LimitSteeringAngle(steering_angle, ConvertDegToRad(30));
+                        push(std::pair<float, float>(FindStepSize(pred, steering_angle, goal, fixed_step_size), steering_angle));
+                    }
+                    else
+                    {
+                        float current_angle = pair.second.first;
+                        float steering_angle_step_size = ConvertDegToRad(5);
+                        while (current_angle <= GetAngleRangeEnd(pair.second))
+                        {
+                            steering_angle = RadNormalization(current_angle - pred.t);
+                            steering_angle = LimitSteeringAngle(steering_angle, ConvertDegToRad(30));
+                            push(std::pair<float, float>(FindStepSize(pred, steering_angle, goal, fixed_step_size), steering_angle));
+                            current_angle += steering_angle_step_size;
+                        }
+                    }
+                }
+            }
+            else
+            {
+                if (P.add_one_more_successor && !P.add_one_more_successor_only_in_free_angle_range)
+                    push(AddOneMoreStepSizeAndSteeringAngle(steering_angle_toward_goal,
+                                                            FindStepSize(pred, steering_angle_toward_goal, goal, fixed_step_size), pred, goal));
+                if (P.steering_angle_towards_free_angle_range_for_obstacle_angle_range)
+                {
+                    float closest_angle = IsCloseToFreeAngleRange(available_angle_range_vec, pair.second.first, GetAngleRangeEnd(pair.second));
+                    steering_angle = RadNormalization(closest_angle - pred.t);
+                    steering_angle = LimitSteeringAngle(steering_angle, ConvertDegToRad(30));
+                    push(std::pair<float, float>(FindStepSize(pred, steering_angle, goal, fixed_step_size), steering_angle));
+                }
+                else
+                {
+                    steering_angle = RadNormalization(pair.second.first - pred.t);
+                    steering_angle = LimitSteeringAngle(steering_angle, ConvertDegToRad(30));
+                    push(std::pair<float, float>(FindStepSize(pred, steering_angle, goal, fixed_step_size), steering_angle));
+                    steering_angle = RadNormalization(pair.second.first + pair.second.second - pred.t);
+                    push(std::pair<float, float>(FindStepSize(pred, steering_angle, goal, fixed_step_size), steering_angle));
+                }
+            }
+        }
+        (void)number_of_successor;
+        return out;
+    }
+    // src/collisiondetection.cpp:1383-1401
+    std::vector<std::pair<float, float>> FindStepSizeAndSteeringAngle(const Node3D &pred, const Node3D &start, const Node3D &goal,
+                                                                      int number_of_successor, float step_size)
+    {
+        float distance_start_to_goal = GetDistance(start, goal);
+        std::vector<std::pair<float, AngleRange>> available_angle_range_vec = FindFreeAngleRangeAndObstacleAngleRange(pred);
+        return SelectStepSizeAndSteeringAngle(available_angle_range_vec, pred, goal, number_of_successor, step_size, distance_start_to_goal);
     }
 
     // ----------------------------------------------- collision (mode POLYGON)
@@ -1655,14 +2202,34 @@ struct Ctx
     }
 
     // src/hybrid_a_star.cpp:540-657 (fixed step branch :600-621, reverse :629-654)
-    std::vector<std::pair<float, float>> stepSteerPairs(const Node3D &pred, const Node3D &goal) const
+    std::vector<std::pair<float, float>> stepSteerPairs(const Node3D &pred, const Node3D &goal, const Node3D &start)
     {
         std::vector<std::pair<float, float>> v;
         float distance_to_goal = GetDistance(pred, goal);
-        float step_size = 0.2;
-        float first = (step_size > distance_to_goal) ? distance_to_goal : step_size;
-        for (float a : FormSteeringAngleVec(P.steering_angle, P.number_of_successors))
-            v.emplace_back(first, a);
+        if (P.adaptive_steering_angle_and_step_size) // :547-584
+        {
+            float current_normalized_obstacle_density = GetNormalizedObstacleDensity(pred);
+            if (current_normalized_obstacle_density > P.constant_density)
+            {
+                float first = (resolution_ > distance_to_goal) ? distance_to_goal : resolution_;
+                for (float a : FormSteeringAngleVec(P.steering_angle, P.number_of_successors))
+                    v.emplace_back(first, a);
+            }
+            else
+                v = FindStepSizeAndSteeringAngle(pred, start, goal, P.number_of_successors, resolution_);
+        }
+        else if (P.adaptive_step_size) // :585-599
+        {
+            for (float a : FormSteeringAngleVec(P.steering_angle, P.number_of_successors))
+                v.emplace_back(FindStepSize(pred, a, goal, resolution_), a);
+        }
+        else // :600-621
+        {
+            float step_size = 0.2;
+            float first = (step_size > distance_to_goal) ? distance_to_goal : step_size;
+            for (float a : FormSteeringAngleVec(P.steering_angle, P.number_of_successors))
+                v.emplace_back(first, a);
+        }
         if (P.reverse)
         {
             float rstep = -0.2;
@@ -1673,10 +2240,10 @@ struct Ctx
         return v;
     }
     // src/hybrid_a_star.cpp:659-756; emits only traversable successors
-    void createSuccessors(const Node3D &pred, int pred_id, const Node3D &goal, std::vector<Node3D> &out, int *n_checked)
+    void createSuccessors(const Node3D &pred, int pred_id, const Node3D &goal, const Node3D &start, std::vector<Node3D> &out, int *n_checked)
     {
         out.clear();
-        for (const auto &pair : stepSteerPairs(pred, goal))
+        for (const auto &pair : stepSteerPairs(pred, goal, start))
         {
             bool reverse_flag = pair.first < 0;
             if ((double)m_fabsf(pair.first) <= 1e-3)
@@ -2109,7 +2676,7 @@ struct Ctx
                     return;
                 }
             }
-            createSuccessors(nPred, pid, goal, succ, &res->successors);
+            createSuccessors(nPred, pid, goal, start, succ, &res->successors);
             for (Node3D &nSucc : succ)
             {
                 // DuplicateCheck, src/hybrid_a_star.cpp:968-980
@@ -2179,6 +2746,8 @@ int orc_set_costmap(void *h, const uint8_t *charmap, uint32_t w, uint32_t hgt, d
     c->translateCostmap();
     c->SetObstacleVec();
     c->SetInRangeObstacle();
+    if (c->P.adaptive_step_size || c->P.adaptive_steering_angle_and_step_size)
+        c->buildAdaptiveMaps();
     c->buildFootprintTable();
     if (build_table)
         c->buildTable(c->P.curve_type, nthreads);
@@ -2240,11 +2809,63 @@ int orc_footprint_table(void *h, int32_t *out, size_t cap)
 int orc_num_successors(void *h)
 {
     Ctx *c = (Ctx *)h;
+    if (c->P.adaptive_steering_angle_and_step_size)
+        return HYAS_ADAPTIVE_SLOTS;
     return (int)orc::FormSteeringAngleVec(c->P.steering_angle, c->P.number_of_successors).size() + (c->P.reverse ? 1 : 0);
 }
+// adaptive maps of one grid cell (key = GetNode3DIndexOnGridMap): min distance, normalised density and up to cap
+// {distance, start, range} triples of distance_angle_range_map_; returns the number of ranges, -1 for an unknown key
+int orc_adaptive_cell(void *h, uint32_t key, float *min_distance, float *density, float *ranges3, int cap, int cut)
+{
+    Ctx *c = (Ctx *)h;
+    auto it = c->distance_angle_range_map_.find(key);
+    if (it == c->distance_angle_range_map_.end())
+        return -1;
+    std::vector<std::pair<float, orc::AngleRange>> list = it->second;
+    if (cut) // FindFreeAngleRangeAndObstacleAngleRange of a node in this cell: the cell's corner stands in for it
+    {
+        orc::Node3D nd;
+        nd.x = c->origin_x_ + (float)(key % c->cm.w) * c->resolution_, nd.y = c->origin_y_ + (float)(key / c->cm.w) * c->resolution_;
+        if (c->GetNode3DIndexOnGridMap(nd.x, nd.y) != key)
+            return -2;
+        list = c->FindFreeAngleRangeAndObstacleAngleRange(nd);
+    }
+    *min_distance = c->min_distance_map_.count(key) ? c->min_distance_map_[key] : -1.f;
+    *density = c->normalized_obstacle_density_map_.count(key) ? c->normalized_obstacle_density_map_[key] : -1.f;
+    int k = 0;
+    for (const auto &e : list)
+    {
+        if (k < cap)
+            ranges3[3 * k] = e.first, ranges3[3 * k + 1] = e.second.first, ranges3[3 * k + 2] = e.second.second;
+        ++k;
+    }
+    return k;
+}
+// the {step size, steering angle} pairs CreateSuccessor would try for one node, reverse pair included
+int orc_step_steer_pairs(void *h, const hyas_node *pred, const hyas_goal *goal, const hyas_goal *start, float *pairs2, int cap)
+{
+    Ctx *c = (Ctx *)h;
+    orc::Node3D p, g, st;
+    p.x = pred->x, p.y = pred->y, p.t = pred->t;
+    g.x = goal->x, g.y = goal->y, g.t = goal->t;
+    st.x = start->x, st.y = start->y, st.t = start->t;
+    auto v = c->stepSteerPairs(p, g, st);
+    for (int k = 0; k < (int)v.size() && k < cap; ++k)
+        pairs2[2 * k] = v[k].first, pairs2[2 * k + 1] = v[k].second;
+    return (int)v.size();
+}
 
+int orc_expand_batch_from(void *h, const hyas_node *preds, const hyas_goal *goals, const hyas_goal *starts, const float *twod, size_t n,
+                          hyas_succ *out, uint8_t *count);
 int orc_expand_batch(void *h, const hyas_node *preds, const hyas_goal *goals, const float *twod, size_t n,
                      hyas_succ *out, uint8_t *count)
+{
+    return orc_expand_batch_from(h, preds, goals, nullptr, twod, n, out, count);
+}
+// starts[i] (optional): the start pose of the search pair i belongs to; the adaptive steering selection weighs with the
+// start-goal distance (src/collisiondetection.cpp:1389).  Without it the goal stands in (distance 0).
+int orc_expand_batch_from(void *h, const hyas_node *preds, const hyas_goal *goals, const hyas_goal *starts, const float *twod, size_t n,
+                          hyas_succ *out, uint8_t *count)
 {
     Ctx *c = (Ctx *)h;
     const int K = orc_num_successors(h);
@@ -2256,9 +2877,12 @@ int orc_expand_batch(void *h, const hyas_node *preds, const hyas_goal *goals, co
         orc::Node3D p, g;
         p.x = preds[i].x, p.y = preds[i].y, p.t = preds[i].t, p.g = preds[i].g, p.prim = preds[i].prim;
         g.x = goals[i].x, g.y = goals[i].y, g.t = goals[i].t;
+        orc::Node3D st = g;
+        if (starts)
+            st.x = starts[i].x, st.y = starts[i].y, st.t = starts[i].t;
         if (twod)
             td.assign(twod + i * cells, twod + (i + 1) * cells);
-        c->createSuccessors(p, -1, g, succ, nullptr);
+        c->createSuccessors(p, -1, g, st, succ, nullptr);
         count[i] = (uint8_t)succ.size();
         for (int k = 0; k < K; ++k)
         {
@@ -2491,6 +3115,32 @@ double orc_utility(int op, const float *a)
         return RadNormalization(a[0]);
     case 17:
         return ConvertDegToRad(a[0]);
+    // angle ranges: arguments in degrees, converted as the reference's tests do (ConvertDegToRad of a float)
+    case 18:
+        return IsOverlap(AngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1])), AngleRange(ConvertDegToRad(a[2]), ConvertDegToRad(a[3])));
+    case 19:
+        return IsAngleRangeInclude(AngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1])), AngleRange(ConvertDegToRad(a[2]), ConvertDegToRad(a[3])));
+    case 20:
+        return IsAngleRangeInclude(AngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1])), ConvertDegToRad(a[2]));
+    case 21: // include test against the end of a second range
+        return IsAngleRangeInclude(AngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1])),
+                                   GetAngleRangeEnd(AngleRange(ConvertDegToRad(a[2]), ConvertDegToRad(a[3]))));
+    case 22:
+        return ConvertRadToDeg(FindAngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1]))[0].first);
+    case 23:
+        return ConvertRadToDeg(GetAngleRangeEnd(FindAngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1]))[0]));
+    case 24:
+        return FindCommonAngleRange(AngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1])), AngleRange(ConvertDegToRad(a[2]), ConvertDegToRad(a[3]))).first;
+    case 25:
+        return GetAngleRangeEnd(FindCommonAngleRange(AngleRange(ConvertDegToRad(a[0]), ConvertDegToRad(a[1])), AngleRange(ConvertDegToRad(a[2]), ConvertDegToRad(a[3]))));
+    case 26:
+        return GetAngleDistance(ConvertDegToRad(a[0]), AngleRange(ConvertDegToRad(a[1]), ConvertDegToRad(a[2])));
+    case 27:
+        return IsEqual(ConvertDegToRad(a[0]), ConvertDegToRad(a[1]));
+    case 28:
+        return GetDistanceFromPolygonToPointAtAngle(CreatePolygon(P(0)), P(1), ConvertDegToRad(a[4]));
+    case 29: // rectangle {origin, width, height}, point, angle in rad
+        return GetDistanceFromPolygonToPointAtAngle(CreatePolygon(P(0), a[5], a[6]), P(1), a[4]);
     default:
         return -12345;
     }

@@ -78,7 +78,7 @@ EXPORTS = [
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
     "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats", "hyas_nodes_in_device_memory",
-    "hyas_table_install_noalloc_dev", "hyas_shortcut_batch",
+    "hyas_table_install_noalloc_dev", "hyas_shortcut_batch", "hyas_expand_batch_from", "hyas_adaptive_cell",
 ]
 
 _lib = None
@@ -253,7 +253,9 @@ class Hyas:
     def twod_size(self):
         return self._check(self.L.hyas_twod_size(self.h), "hyas_twod_size")
 
-    def expand(self, preds, goals, twod=None):
+    def expand(self, preds, goals, twod=None, starts=None):
+        """Successors of n (node, goal) pairs; starts = the start pose of the search each pair belongs to (needed by
+        adaptive_steering_angle_and_step_size).  count 0xFF marks a node with more candidates than its slots hold."""
         preds = np.ascontiguousarray(preds, NODE_DT)
         goals = np.ascontiguousarray(goals, GOAL_DT)
         n = preds.shape[0]
@@ -265,9 +267,23 @@ class Hyas:
             twod = np.ascontiguousarray(twod, np.float32)
             assert twod.size == n * self.twod_size()
             tp = _vp(twod)
-        self._check(self.L.hyas_expand_batch(self.h, _vp(preds), _vp(goals), tp, n, _vp(out), _vp(cnt)),
-                    "hyas_expand_batch")
+        if starts is not None:
+            starts = np.ascontiguousarray(starts, GOAL_DT)
+            assert starts.shape[0] == n
+            self._check(self.L.hyas_expand_batch_from(self.h, _vp(preds), _vp(goals), _vp(starts), tp, n, _vp(out), _vp(cnt)),
+                        "hyas_expand_batch_from")
+        else:
+            self._check(self.L.hyas_expand_batch(self.h, _vp(preds), _vp(goals), tp, n, _vp(out), _vp(cnt)),
+                        "hyas_expand_batch")
         return out, cnt
+
+    def adaptive_cell(self, key, cap=256):
+        """(minimum obstacle distance, normalised density, [(distance, start, width), ...]) of one grid key."""
+        md, de = C.c_float(), C.c_float()
+        r = np.zeros((cap, 3), np.float32)
+        n = self._check(self.L.hyas_adaptive_cell(self.h, C.c_uint32(int(key)), C.byref(md), C.byref(de), _vp(r), C.c_size_t(cap)),
+                        "hyas_adaptive_cell")
+        return md.value, de.value, r[:min(n, cap)].copy()
 
     def shot(self, nodes, goals):
         nodes = np.ascontiguousarray(nodes, NODE_DT)

@@ -57,6 +57,11 @@ struct hyas_ctx
     float *d_seg_db = nullptr;
     uint32_t *d_pose_off = nullptr, *d_seg_off = nullptr;
     uint16_t *d_pose_idx = nullptr, *d_seg_idx = nullptr;
+    // adaptive step size / steering: per grid key the angle ranges (CSR), normalised density, minimum obstacle distance
+    uint32_t *d_ad_off = nullptr;
+    float *d_ad_rng = nullptr, *d_ad_density = nullptr;
+    std::vector<uint32_t> ad_off;
+    std::vector<float> ad_rng, ad_density, ad_min_distance;
     size_t n_pose_entries = 0, n_seg_entries = 0;
 
     // growable scratch: device + pinned host, reused by every batched call

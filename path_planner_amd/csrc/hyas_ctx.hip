@@ -1,6 +1,7 @@
 // hyas_ctx.hip -- C ABI (include/hyas.h): context life cycle, map ingest,
 // heuristic-table build and the batched kernel entry points.
 #include "hyas_ctx.h"
+#include "hyas_adaptive.h"
 #include "hyas_prune.h"
 
 #include <algorithm>
@@ -431,7 +432,8 @@ static void set_resolution(DevMap &m, double res, double ox, double oy)
 static void free_map(hyas_ctx *c)
 {
     void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
-                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack, c->d_seg_db, c->d_fp_win};
+                    c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack, c->d_seg_db, c->d_fp_win,
+                    c->d_ad_off, c->d_ad_rng, c->d_ad_density};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -439,6 +441,8 @@ static void free_map(hyas_ctx *c)
     c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
     c->d_pose_off = c->d_seg_off = nullptr, c->d_pose_idx = c->d_seg_idx = nullptr;
     c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr, c->d_seg_db = nullptr, c->d_fp_win = nullptr;
+    c->d_ad_off = nullptr, c->d_ad_rng = nullptr, c->d_ad_density = nullptr;
+    c->ad_off.clear(), c->ad_rng.clear(), c->ad_density.clear(), c->ad_min_distance.clear();
     c->tab_xs.clear(), c->tab_ys.clear(), c->tab_ts.clear();
     c->table_size = 0, c->twod_size = 0, c->seg_cap = 0;
     c->have_map = c->have_table = false;
@@ -555,7 +559,7 @@ void hyas_default_params(hyas_params *p)
     std::memset(p, 0, sizeof *p);
     p->position_resolution = 10, p->headings = 72, p->cd_min_turning_radius = 6, p->curve_type = 0;
     p->vehicle_width = 1, p->vehicle_length = 2, p->obstacle_detection_range = 5, p->map_boundary_obstacle = 0;
-    p->number_of_successors = 3, p->adaptive_steering_angle_and_step_size = 0, p->adaptive_step_size = 0;
+    p->number_of_successors = 3, p->adaptive_steering_angle_and_step_size = 0, p->adaptive_step_size = 1; // include/parameter_manager.h:129-131
     p->analytical_expansion_every_point = 1, p->analytical_expansion = 1;
     p->penalty_turning = 1.05f, p->penalty_reverse = 1, p->penalty_change_of_direction = 2, p->reverse = 0;
     p->max_iterations = 10000, p->steering_angle = 5, p->goal_range = 1e-3f, p->tie_breaker = 0.01f;
@@ -569,12 +573,15 @@ void hyas_hot_path_params(hyas_params *p)
 {
     hyas_default_params(p);
     p->curve_type = HYAS_CURVE_RS, p->number_of_successors = 5, p->steering_angle = 5, p->reverse = 1, p->short_cut = 0;
+    p->adaptive_step_size = 0; // the fixed-step branch, src/hybrid_a_star.cpp:600-621
 }
 
 static bool params_ok(const hyas_params *p, std::string &why)
 {
-    if (p->adaptive_steering_angle_and_step_size || p->adaptive_step_size)
-        why = "adaptive step/steering modes are not part of this path (fixed-step branch only)";
+    if ((p->adaptive_steering_angle_and_step_size || p->adaptive_step_size) && p->consider_steering_angle_range_for_obstacle_density)
+        why = "consider_steering_angle_range_for_obstacle_density is not supported (the obstacle density is taken per grid cell)";
+    else if ((p->adaptive_steering_angle_and_step_size || p->adaptive_step_size) && !(p->obstacle_detection_range > 0))
+        why = "the adaptive modes need a positive obstacle_detection_range";
     else if (p->map_boundary_obstacle)
         why = "map_boundary_obstacle is not supported";
     else if (p->piecewise_cubic_bezier_interpolation)
@@ -696,7 +703,7 @@ void hyas_destroy(hyas_ctx *c)
 
 const char *hyas_last_error(const hyas_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
-int hyas_num_successors(const hyas_ctx *c) { return c ? c->dm.n_succ : HYAS_EINVAL; }
+int hyas_num_successors(const hyas_ctx *c) { return c ? c->dm.n_slots : HYAS_EINVAL; }
 
 static void fill_motion_set(hyas_ctx *c)
 {
@@ -714,6 +721,13 @@ static void fill_motion_set(hyas_ctx *c)
     if (c->P.reverse)
         m.succ_steer[k] = 0, m.succ_reverse[k] = 1, ++k;
     m.n_succ = k;
+    // CreateSuccessor's branch (src/hybrid_a_star.cpp:547-600): the combined mode wins over the step-only mode
+    m.ad_mode = c->P.adaptive_steering_angle_and_step_size ? 1 : c->P.adaptive_step_size ? 2 : 0;
+    m.n_slots = m.ad_mode == 1 ? HYAS_ADAPTIVE_SLOTS : k;
+    m.ad_range = c->P.obstacle_detection_range, m.ad_constant_density = c->P.constant_density;
+    m.ad_one_more = c->P.add_one_more_successor != 0, m.ad_one_more_free_only = c->P.add_one_more_successor_only_in_free_angle_range != 0;
+    m.ad_towards_free = c->P.steering_angle_towards_free_angle_range_for_obstacle_angle_range != 0;
+    m.ad_fixed_number = c->P.fixed_number_of_steering_angle_in_free_angle_range != 0;
     m.pen_turn = c->P.penalty_turning, m.pen_rev = c->P.penalty_reverse, m.pen_cod = c->P.penalty_change_of_direction;
     m.shot_rho = c->P.min_turning_radius;
     m.curve_type = c->P.curve_type;
@@ -814,6 +828,132 @@ int hyas_table_install_noalloc_dev(hyas_ctx *c, int curve, const float *raw_dev)
     return HYAS_OK;
 }
 
+// The per-costmap part of the adaptive step size / steering modes: the hybrid_astar branch of
+// CollisionDetection::UpdateGrid (src/collisiondetection.cpp:39-46).  The sweep of every cell corner (361 rays against
+// the corner's in-range obstacles) and the minimum obstacle distance run on the GPU in tiles of whole x columns; the
+// run-length pass over each sweep, the cut to the circle and the density normalisation are a few operations per
+// angle and run here.  owner[key] = the first loop position (x outer, y inner) that maps to a grid key: the
+// reference's maps keep what that position emplaced.
+static int build_adaptive_maps(hyas_ctx *c, const std::vector<float> &xs, const std::vector<float> &ys, const std::vector<int64_t> &owner)
+{
+    DevMap &m = c->dm;
+    const size_t cells = (size_t)c->w * c->h, nys = ys.size();
+    const std::vector<float> angles = ad::sweep_angles();
+    const size_t n_ang = angles.size();
+    float *d_xs = nullptr, *d_ys = nullptr, *d_ang = nullptr, *d_dist = nullptr, *d_min = nullptr;
+    const size_t cols_per_tile = std::max<size_t>(1, std::min<size_t>(xs.size(), ((size_t)64 << 20) / std::max<size_t>(nys * n_ang * sizeof(float), 1)));
+    std::vector<float> dist(cols_per_tile * nys * n_ang), mind(xs.size() * nys);
+    int rc = upload(c, d_xs, xs);
+    if (rc == HYAS_OK)
+        rc = upload(c, d_ys, ys);
+    if (rc == HYAS_OK)
+        rc = upload(c, d_ang, angles);
+    hipError_t e = hipSuccess;
+    if (rc == HYAS_OK && (e = hipMalloc((void **)&d_dist, dist.size() * sizeof(float))) != hipSuccess)
+        rc = hip_fail(c, e, "hipMalloc(sweep distances)");
+    if (rc == HYAS_OK && (e = hipMalloc((void **)&d_min, mind.size() * sizeof(float))) != hipSuccess)
+        rc = hip_fail(c, e, "hipMalloc(minimum distances)");
+    if (rc == HYAS_OK)
+    {
+        launch_min_distance(m, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)nys, d_min, c->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(mind.data(), d_min, mind.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess)
+            rc = hip_fail(c, e, "minimum distances");
+    }
+    // min_distance_map_.emplace(key, ...): the owner's value (src/collisiondetection.cpp:1437)
+    c->ad_min_distance.assign(cells, 1000.f);
+    for (size_t key = 0; key < cells; ++key)
+        if (owner[key] >= 0)
+            c->ad_min_distance[key] = mind[(size_t)owner[key]];
+    std::vector<std::vector<ad::Range>> ranges(cells);
+    std::vector<std::vector<uint32_t>> keys_of_col(xs.size());
+    for (size_t key = 0; key < cells; ++key)
+        if (owner[key] >= 0)
+            keys_of_col[(size_t)owner[key] / nys].push_back((uint32_t)key);
+    for (size_t i0 = 0; rc == HYAS_OK && i0 < xs.size(); i0 += cols_per_tile)
+    {
+        const size_t ni = std::min(cols_per_tile, xs.size() - i0);
+        launch_sweep_distance(m, d_xs + i0, (uint32_t)ni, d_ys, (uint32_t)nys, d_ang, (uint32_t)n_ang, c->P.obstacle_detection_range, d_dist, c->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dist.data(), d_dist, ni * nys * n_ang * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess)
+        {
+            rc = hip_fail(c, e, "sweep distances");
+            break;
+        }
+        for (size_t i = i0; i < i0 + ni; ++i)
+            for (uint32_t key : keys_of_col[i])
+            {
+                const float *d = &dist[((size_t)owner[key] - i0 * nys) * n_ang];
+                ad::ranges_of_sweep(angles.data(), d, n_ang, c->ad_min_distance[key], c->P.obstacle_detection_range, ranges[key]);
+                ad::cut_to_circle(ranges[key]); // FindFreeAngleRangeAndObstacleAngleRange, the same for every node of the cell
+            }
+    }
+    for (float *p : {d_xs, d_ys, d_ang, d_dist, d_min})
+        if (p)
+            (void)hipFree(p);
+    if (rc != HYAS_OK)
+        return rc;
+    // BuildObstacleDensityMap (the per-cell count, :1034-1049) and BuildNormalizedObstacleDensityMap (:1110-1151)
+    float max_density = 0, min_density = 1000000;
+    for (size_t key = 0; key < cells; ++key)
+        if (owner[key] >= 0)
+        {
+            const float d = (float)(c->cell_off[key + 1] - c->cell_off[key]);
+            if (d > max_density)
+                max_density = d;
+            if (d < min_density)
+                min_density = d;
+        }
+    const float delta = 0.01f;
+    c->ad_density.assign(cells, 0.f);
+    c->ad_off.assign(cells + 1, 0);
+    c->ad_rng.clear();
+    for (size_t key = 0; key < cells; ++key)
+    {
+        c->ad_off[key] = (uint32_t)(c->ad_rng.size() / 3);
+        if (owner[key] < 0)
+            continue;
+        c->ad_density[key] = ((float)(c->cell_off[key + 1] - c->cell_off[key]) - min_density) / (max_density - min_density + delta);
+        for (const ad::Range &r : ranges[key])
+            c->ad_rng.push_back(r.dist), c->ad_rng.push_back(r.start), c->ad_rng.push_back(r.range);
+    }
+    c->ad_off[cells] = (uint32_t)(c->ad_rng.size() / 3);
+    if ((rc = upload(c, c->d_ad_off, c->ad_off)) != HYAS_OK || (rc = upload(c, c->d_ad_rng, c->ad_rng)) != HYAS_OK ||
+        (rc = upload(c, c->d_ad_density, c->ad_density)) != HYAS_OK)
+        return rc;
+    m.ad_off = c->d_ad_off, m.ad_rng = c->d_ad_rng, m.ad_density = c->d_ad_density;
+    return HYAS_OK;
+}
+
+// The adaptive maps of one grid key (0 <= key < w * h), for inspection: minimum obstacle distance, normalised density
+// and up to cap {label distance, start, width} angle ranges as FindFreeAngleRangeAndObstacleAngleRange returns them
+// for a node in that cell.  Returns the number of ranges.
+int hyas_adaptive_cell(hyas_ctx *c, uint32_t key, float *min_distance, float *density, float *ranges3, size_t cap)
+{
+    if (!c || !c->have_map || c->grid_only)
+        return HYAS_ESTATE;
+    if (c->dm.ad_mode == 0)
+        return c->fail(HYAS_ESTATE, "the context was created without an adaptive mode");
+    if ((uint64_t)key >= (uint64_t)c->w * c->h)
+        return c->fail(HYAS_EINVAL, "grid key outside the map");
+    if (min_distance)
+        *min_distance = c->ad_min_distance[key];
+    if (density)
+        *density = c->ad_density[key];
+    const uint32_t b = c->ad_off[key], n = c->ad_off[key + 1] - b;
+    if (ranges3)
+        std::memcpy(ranges3, &c->ad_rng[3 * (size_t)b], std::min<size_t>(n, cap) * 3 * sizeof(float));
+    return (int)n;
+}
+
 int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h, double res, double ox, double oy, int build_table)
 {
     if (!c)
@@ -858,18 +998,18 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     const size_t cells = (size_t)w * h;
     c->cell_off.assign(cells + 1, 0);
     c->cell_idx.clear();
+    // in_range_obstacle_map_.emplace(key, list): the first loop position
+    // that maps to a key keeps it (src/collisiondetection.cpp:345)
+    std::vector<int64_t> owner(cells, -1);
+    for (size_t i = 0; i < xs.size(); ++i)
+        for (size_t j = 0; j < ys.size(); ++j)
+        {
+            uint32_t key = grid_key(m, xs[i], ys[j]);
+            if (key < cells && owner[key] < 0)
+                owner[key] = (int64_t)(i * ys.size() + j);
+        }
     if (!c->quads.empty())
     {
-        // in_range_obstacle_map_.emplace(key, list): the first loop position
-        // that maps to a key keeps it (src/collisiondetection.cpp:345)
-        std::vector<int64_t> owner(cells, -1);
-        for (size_t i = 0; i < xs.size(); ++i)
-            for (size_t j = 0; j < ys.size(); ++j)
-            {
-                uint32_t key = grid_key(m, xs[i], ys[j]);
-                if (key < cells && owner[key] < 0)
-                    owner[key] = (int64_t)(i * ys.size() + j);
-            }
         // The range flags (one byte per cell corner and quad) are produced on the GPU in tiles of whole x columns of
         // at most 64 MiB, so that the staging does not grow with cells x quads.
         const size_t nq = c->quads.size(), per_col = ys.size() * nq;
@@ -929,6 +1069,10 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
         c->cell_off[cells] = (uint32_t)c->cell_idx.size();
     }
     if ((rc = upload(c, c->d_cell_off, c->cell_off)) != HYAS_OK || (rc = upload(c, c->d_cell_idx, c->cell_idx)) != HYAS_OK)
+        return rc;
+    m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
+    m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx;
+    if (m.ad_mode != 0 && (rc = build_adaptive_maps(c, xs, ys, owner)) != HYAS_OK)
         return rc;
     {
         // successor steps are 0.2 m, curve samples 0.1 x resolution apart
@@ -1167,7 +1311,7 @@ int hyas_flood(hyas_ctx *c, const hyas_goal *goal, float *out)
 
 // Shared body of hyas_expand_batch / hyas_shot_batch: one kernel launch over
 // n independent (node, goal) pairs.
-static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals, const float *twod, size_t n, int shoot, uint8_t *ok,
+static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals, const hyas_goal *starts, const float *twod, size_t n, int shoot, uint8_t *ok,
                     float *len, hyas_succ *succ, uint8_t *count)
 {
     if (!c || !c->have_map || !c->have_table)
@@ -1177,7 +1321,7 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
     if (n > 0x7fffffffu)
         return c->fail(HYAS_ERANGE, "too many nodes in one call");
     HYAS_HIP(c, hipSetDevice(c->device));
-    const int K = c->dm.n_succ;
+    const int K = c->dm.n_slots;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_in = take(n * sizeof(StepIn)), o_goal = take(n * sizeof(hyas_goal)), o_succ = take(n * K * sizeof(hyas_succ)),
@@ -1190,7 +1334,15 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
     char *hs = (char *)c->h_scratch, *ds = (char *)c->d_scratch;
     StepIn *h_in = (StepIn *)(hs + o_in);
     for (size_t i = 0; i < n; ++i)
-        h_in[i] = StepIn{nodes[i].x, nodes[i].y, nodes[i].t, nodes[i].g, nodes[i].prim, (uint32_t)i, (uint32_t)shoot, 0};
+    {
+        uint32_t dsg = 0;
+        if (starts) // Utility::GetDistance(start, goal)
+        {
+            const float d = normf(sub(f2(starts[i].x, starts[i].y), f2(goals[i].x, goals[i].y)));
+            std::memcpy(&dsg, &d, sizeof d);
+        }
+        h_in[i] = StepIn{nodes[i].x, nodes[i].y, nodes[i].t, nodes[i].g, nodes[i].prim, (uint32_t)i, (uint32_t)shoot, dsg};
+    }
     std::memcpy(hs + o_goal, goals, n * sizeof(hyas_goal));
     HYAS_HIP(c, hipMemcpyAsync(ds + o_in, hs + o_in, o_succ - o_in, hipMemcpyHostToDevice, c->stream));
     if (twod)
@@ -1211,7 +1363,10 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
         std::memcpy(succ, hs + o_succ, n * K * sizeof(hyas_succ));
     if (count)
         for (size_t i = 0; i < n; ++i)
-            count[i] = ((const uint8_t *)(hs + o_cnt))[i] & 15;
+        {
+            const uint8_t v = ((const uint8_t *)(hs + o_cnt))[i];
+            count[i] = v == 0xFF ? v : (v & 15);
+        }
     if (ok)
         std::memcpy(ok, hs + o_ok, n);
     if (len)
@@ -1223,14 +1378,24 @@ int hyas_expand_batch(hyas_ctx *c, const hyas_node *preds, const hyas_goal *goal
 {
     if (c && n && (!preds || !goals || !out || !count))
         return c->fail(HYAS_EINVAL, "null buffer");
-    return run_step(c, preds, goals, twod, n, 0, nullptr, nullptr, out, count);
+    if (c && c->dm.ad_mode == 1)
+        return c->fail(HYAS_EINVAL, "adaptive_steering_angle_and_step_size needs the start pose of each search: use hyas_expand_batch_from");
+    return run_step(c, preds, goals, nullptr, twod, n, 0, nullptr, nullptr, out, count);
+}
+
+int hyas_expand_batch_from(hyas_ctx *c, const hyas_node *preds, const hyas_goal *goals, const hyas_goal *starts, const float *twod, size_t n,
+                           hyas_succ *out, uint8_t *count)
+{
+    if (c && n && (!preds || !goals || !starts || !out || !count))
+        return c->fail(HYAS_EINVAL, "null buffer");
+    return run_step(c, preds, goals, starts, twod, n, 0, nullptr, nullptr, out, count);
 }
 
 int hyas_shot_batch(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals, size_t n, uint8_t *ok, float *len)
 {
     if (c && n && (!nodes || !goals || !ok || !len))
         return c->fail(HYAS_EINVAL, "null buffer");
-    return run_step(c, nodes, goals, nullptr, n, 1, ok, len, nullptr, nullptr);
+    return run_step(c, nodes, goals, nullptr, nullptr, n, 1, ok, len, nullptr, nullptr);
 }
 
 int hyas_shortcut_batch(hyas_ctx *c, const float *paths_xyt, const uint32_t *offsets, size_t n_paths, uint32_t *out_idx, uint32_t *out_n)

@@ -132,6 +132,15 @@ struct DevMap
     // cubic Bezier shot: the same for `x += 0.1 * res` (src/hybrid_a_star.cpp:477-499)
     const float *seg_bz;
     uint32_t seg_bz_cap;
+    // adaptive step size / steering (hyas_adaptive.h): 0 off, 1 adaptive_steering_angle_and_step_size, 2 adaptive_step_size
+    int32_t ad_mode;
+    int32_t n_slots;         // successor slots per node in the step's output: n_succ, or HYAS_ADAPTIVE_SLOTS in mode 1
+    const uint32_t *ad_off;  // w*h + 1 entries: ranges of grid key k are ad_rng[3 * ad_off[k] .. 3 * ad_off[k + 1])
+    const float *ad_rng;     // {distance, start, range} triples
+    const float *ad_density; // normalised obstacle density per grid key
+    float ad_range;          // obstacle_detection_range: the distance that marks a free range
+    float ad_constant_density;
+    int32_t ad_one_more, ad_one_more_free_only, ad_towards_free, ad_fixed_number;
 };
 
 // ---------------------------------------------------------------- Utility::
@@ -712,26 +721,12 @@ HD float heuristic(const DevMap &m, float x, float y, float t, float gx, float g
 // ------------------------------------------------------------- successors
 // src/hybrid_a_star.cpp:659-756 for motion-set entry k of node (x,y,t).
 // Returns false when the step is too small to create a successor (:681).
-HD bool successor_pose(const DevMap &m, float x, float y, float t, float dist_to_goal, int k, float &sx, float &sy, float &st,
-                       int &prim)
+// One {step size, steering angle} pair of CreateSuccessor(pred, vector), src/hybrid_a_star.cpp:667-741.
+HD bool successor_from_pair(float x, float y, float t, float first, float steer, float &sx, float &sy, float &st, int &prim)
 {
-    const bool rev = m.succ_reverse[k] != 0;
-    // :606-614, :634-642
-    float first;
-    if (!rev)
-    {
-        float step = 0.2f;
-        first = (step > dist_to_goal) ? dist_to_goal : step;
-    }
-    else
-    {
-        float step = -0.2f;
-        first = (hy_fabsf(step) > dist_to_goal) ? -dist_to_goal : step;
-    }
     const bool reverse_flag = first < 0;
     if ((double)hy_fabsf(first) <= 1e-3)
         return false;
-    const float steer = m.succ_steer[k];
     const float radius = first / hy_fabsf(steer);
     float dx, dy;
     if (steer < 0)
@@ -758,6 +753,22 @@ HD bool successor_pose(const DevMap &m, float x, float y, float t, float dist_to
     sy = y + dx * sn + dy * ct;
     st = rad_0_2pi(t + steer);
     return true;
+}
+// step of the fixed motion set (:606-614) or of the reverse pair (:634-642)
+HD float motion_step(bool rev, float dist_to_goal)
+{
+    if (!rev)
+    {
+        float step = 0.2f;
+        return (step > dist_to_goal) ? dist_to_goal : step;
+    }
+    float step = -0.2f;
+    return (hy_fabsf(step) > dist_to_goal) ? -dist_to_goal : step;
+}
+HD bool successor_pose(const DevMap &m, float x, float y, float t, float dist_to_goal, int k, float &sx, float &sy, float &st,
+                       int &prim)
+{
+    return successor_from_pair(x, y, t, motion_step(m.succ_reverse[k] != 0, dist_to_goal), m.succ_steer[k], sx, sy, st, prim);
 }
 
 // src/hybrid_a_star.cpp:761-811

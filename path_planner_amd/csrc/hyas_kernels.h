@@ -20,6 +20,9 @@ struct StepIn
 void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
 void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
                      uint8_t *flags, hipStream_t s);
+void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,
+                           float *out, hipStream_t s);
+void launch_min_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float *out, hipStream_t s);
 void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,
                      float *out, hipStream_t s);
 void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,

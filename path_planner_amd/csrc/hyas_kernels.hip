@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "hyas_kernels.h"
+#include "hyas_adaptive.h"
 #include "hyas_bezier.h"
 #include "hyas_dubins.h"
 #include "hyas_flood.h"
@@ -309,6 +310,56 @@ __global__ void __launch_bounds__(256) k_in_range(const Quad *__restrict__ quads
         size_t c = i / n_quads;
         F2 p = f2(xs[c / nys], ys[c % nys]);
         flags[i] = dist_quad_point(quads[q], p) < range ? 1 : 0;
+    }
+}
+
+// Adaptive step size / steering, map ingest.  For the cell corner (xs[i], ys[j]) and sweep angle a:
+// CollisionDetection::FindNoCollisionDistance (src/collisiondetection.cpp:973-1011), the nearest hit of the ray among
+// the corner's in-range obstacles, `radius` when none is hit: out[(i * nys + j) * n_ang + a].
+__global__ void __launch_bounds__(256) k_sweep_distance(DevMap m, const float *__restrict__ xs, uint32_t nxs, const float *__restrict__ ys, uint32_t nys,
+                                                        const float *__restrict__ angles, uint32_t n_ang, float radius, float *__restrict__ out)
+{
+    const size_t total = (size_t)nxs * nys * n_ang;
+    const uint32_t cells = m.w * m.h;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    {
+        const uint32_t a = (uint32_t)(e % n_ang);
+        const size_t c = e / n_ang;
+        const F2 p = f2(xs[c / nys], ys[c % nys]);
+        const uint32_t key = grid_key(m, p.x, p.y);
+        float best = radius;
+        if (key < cells)
+            for (uint32_t k = m.cell_off[key]; k < m.cell_off[key + 1]; ++k)
+            {
+                const float t = ad::ray_distance(m.quads[m.cell_idx[k]], p, angles[a]);
+                if (t < 0)
+                    continue;
+                if (best > t)
+                    best = t;
+            }
+        out[e] = best;
+    }
+}
+// CollisionDetection::SetMinDistanceMap (src/collisiondetection.cpp:1403-1447): the nearest of the corner's in-range
+// obstacles, 1000 without any: out[i * nys + j].
+__global__ void __launch_bounds__(256) k_min_distance(DevMap m, const float *__restrict__ xs, uint32_t nxs, const float *__restrict__ ys, uint32_t nys,
+                                                      float *__restrict__ out)
+{
+    const size_t total = (size_t)nxs * nys;
+    const uint32_t cells = m.w * m.h;
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < total; c += (size_t)gridDim.x * blockDim.x)
+    {
+        const F2 p = f2(xs[c / nys], ys[c % nys]);
+        const uint32_t key = grid_key(m, p.x, p.y);
+        float best = 1000;
+        if (key < cells)
+            for (uint32_t k = m.cell_off[key]; k < m.cell_off[key + 1]; ++k)
+            {
+                const float d = dist_quad_point(m.quads[m.cell_idx[k]], p);
+                if (best > d)
+                    best = d;
+            }
+        out[c] = best;
     }
 }
 
@@ -683,32 +734,74 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
     return StepQuads{(const HYAS_LDS Quad *)s_quads, m.quads, nullptr, quads_local, false};
 }
 
-template <int MODE>
+// ADAPT: 0 fixed motion set, 1 adaptive steering angle and step size, 2 adaptive step size (hyas_adaptive.h).
+// With ADAPT == 1 a node has up to HYAS_AD_MAX_PAIRS + 1 candidates: sixteen lanes per node and test, eight nodes per
+// workgroup; the first lane of a node forms the node's {step, steering} list in workgroup memory, then the lanes take
+// one pair each.  count = 0xFF marks a node whose list did not fit.
+template <int ADAPT>
+struct ExpandShape
+{
+    static constexpr int LANES = ADAPT == 1 ? 16 : 8;               // lanes per node and kind of test
+    static constexpr int NODES = EXPAND_THREADS / 2 / LANES;        // nodes per workgroup
+};
+
+template <int MODE, int ADAPT>
 __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__restrict__ in, uint32_t n, const hyas_goal *__restrict__ goals,
                                             const float *__restrict__ twod, uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
                                             unsigned long long *stats, Quad *s_quads, uint32_t block)
 {
+    constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES;
     const int tid = threadIdx.x;
     const StepQuads sq = stage_quads(m, s_quads, tid);
-    __syncthreads();
     __shared__ uint8_t s_pose[EXPAND_THREADS / 2];
-    // eight lanes per node and test; waves 0-1 run the pose tests, waves 2-3 the swept-segment tests
+    __shared__ float s_step[ADAPT == 1 ? NODES : 1][HYAS_AD_MAX_PAIRS], s_steer[ADAPT == 1 ? NODES : 1][HYAS_AD_MAX_PAIRS];
+    __shared__ int s_pairs[ADAPT == 1 ? NODES : 1]; // pairs of the node, -1: too many
+    // LANES lanes per node and test; waves 0-1 run the pose tests, waves 2-3 the swept-segment tests
     // (a wave that mixed the two would run them one after the other)
-    const int lane = tid & 63, sl = tid & 7, local = (tid & (EXPAND_THREADS / 2 - 1)) >> 3;
-    const uint32_t slot = block * (EXPAND_THREADS / 16) + local;
+    const int lane = tid & 63, sl = tid & (LANES - 1), local = (tid & (EXPAND_THREADS / 2 - 1)) / LANES;
+    const uint32_t slot = block * NODES + local;
     const bool live = slot < n;
     const StepIn node = in[live ? slot : 0];
     const hyas_goal goal = goals[node.query];
     const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
-    const int K = m.n_succ;
     const bool pose_lane = tid < EXPAND_THREADS / 2, seg_lane = !pose_lane;
-    bool part_ok = false, evaluated = false;
+    const float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
+    if (ADAPT == 1 && live && pose_lane && sl == 0)
+    {
+        ad::Pairs p;
+        p.step = s_step[local], p.steer = s_steer[local];
+        ad::step_steer_pairs(m, node.x, node.y, node.t, goal.x, goal.y, goal.t, __uint_as_float(node.pad), p);
+        s_pairs[local] = p.overflow ? -1 : p.n;
+    }
+    __syncthreads(); // quads staged, pair lists formed
+    bool part_ok = false, evaluated = false, overflow = false;
     float sx = 0, sy = 0, st = 0;
     int prim = 0;
-    if (live && sl < K)
+    if (live)
     {
-        float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
-        if (successor_pose(m, node.x, node.y, node.t, dist, sl, sx, sy, st, prim))
+        // this lane's candidate: {step, steering angle}
+        bool have = false;
+        float first = 0, steer = 0;
+        if (ADAPT == 1)
+        {
+            const int np = s_pairs[local];
+            overflow = np < 0;
+            const bool reverse = m.succ_reverse[m.n_succ - 1] != 0;
+            if (!overflow && sl < np)
+                have = true, first = s_step[local][sl], steer = s_steer[local][sl];
+            else if (!overflow && sl == np && reverse) // the reverse pair follows the node's list (src/hybrid_a_star.cpp:629-654)
+                have = true, first = motion_step(true, dist), steer = m.succ_steer[m.n_succ - 1];
+        }
+        else if (sl < m.n_succ)
+        {
+            have = true, steer = m.succ_steer[sl];
+            const bool rev = m.succ_reverse[sl] != 0;
+            if (ADAPT == 2 && !rev) // src/hybrid_a_star.cpp:585-599
+                first = ad::find_step_size(m, ad::cell_of(m, node.x, node.y), node.t, steer, dist, m.res_f);
+            else
+                first = motion_step(rev, dist);
+        }
+        if (have && successor_from_pair(node.x, node.y, node.t, first, steer, sx, sy, st, prim))
         {
             evaluated = true;
             if (pose_lane)
@@ -733,22 +826,23 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         s.free = 1;
         s.pad = 0;
     }
-    // compact in motion-set order, as the reference's output vector
-    const unsigned grp = (lane >> 3) * 8;
-    const unsigned mask = (unsigned)((__ballot(ok) >> grp) & 0xFFull);
-    const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & 0xFFull);
+    // compact in candidate order, as the reference's output vector
+    const unsigned grp = (lane / LANES) * LANES;
+    constexpr unsigned long long GROUP = (1ull << LANES) - 1ull;
+    const unsigned mask = (unsigned)((__ballot(ok) >> grp) & GROUP);
+    const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & GROUP);
     if (ok)
     {
         int pos = __popc(mask & ((1u << sl) - 1u));
-        succ[(size_t)slot * m.n_succ + pos] = s;
+        succ[(size_t)slot * m.n_slots + pos] = s;
     }
     const bool writer = live && seg_lane && sl == 0;
     if (writer) // low nibble: emitted successors, high nibble: candidates that got a verdict
-        count[slot] = (uint8_t)(__popc(mask) | (__popc(emask) << 4));
+        count[slot] = overflow ? (uint8_t)0xFF : (uint8_t)(__popc(mask) | (__popc(emask) << 4));
     if (MODE == 1)
     {
         uint32_t walked = (seg_lane && evaluated) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
-        for (int off = 4; off > 0; off >>= 1)
+        for (int off = LANES / 2; off > 0; off >>= 1)
             walked += __shfl_xor(walked, off, 64);
         if (writer)
         {
@@ -1130,14 +1224,14 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     }
 }
 
-template <int MODE>
+template <int MODE, int ADAPT>
 __global__ void __launch_bounds__(ROUND_THREADS) k_expand(DevMap m, const StepIn *__restrict__ in, uint32_t n,
                                                           const hyas_goal *__restrict__ goals,
                                                           const float *__restrict__ twod, // [query][twod_size] or null
                                                           uint8_t *__restrict__ count, hyas_succ *__restrict__ succ, unsigned long long *stats)
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
-    expand_role<MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x);
+    expand_role<MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x);
 }
 
 template <int MODE, int CURVE>
@@ -1156,7 +1250,7 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_shot(DevMap m
 // of node i, the following ceil(n / 16) workgroups the successors of 16 nodes
 // each.  The two parts are independent; the shot workgroups come first because
 // they run longest.
-template <int MODE, int CURVE>
+template <int MODE, int CURVE, int ADAPT>
 __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap m, const StepIn *__restrict__ in, uint32_t n,
                                                                         const hyas_goal *__restrict__ goals, const float *__restrict__ twod,
                                                                         const double *__restrict__ seg_tab, uint32_t seg_cap,
@@ -1168,7 +1262,7 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
     if (blockIdx.x < n) // uniform across the workgroup
         shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
     else
-        expand_role<MODE == 2 ? 0 : MODE>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n);
+        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n);
 }
 
 // The accepted curves of n queries, one workgroup each: samples {x, y, t} of
@@ -1611,6 +1705,21 @@ void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint3
     hipLaunchKernelGGL(k_in_range, dim3(grid_for(total)), dim3(256), 0, s, quads, n_quads, xs, nxs, ys, nys, range, flags);
 }
 
+void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,
+                           float *out, hipStream_t s)
+{
+    const size_t total = (size_t)nxs * nys * n_ang;
+    if (total)
+        hipLaunchKernelGGL(k_sweep_distance, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, m, xs, nxs, ys, nys, angles, n_ang, radius, out);
+}
+
+void launch_min_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float *out, hipStream_t s)
+{
+    const size_t total = (size_t)nxs * nys;
+    if (total)
+        hipLaunchKernelGGL(k_min_distance, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, m, xs, nxs, ys, nys, out);
+}
+
 void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,
                      float *out, hipStream_t s)
 {
@@ -1663,41 +1772,81 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
 {
     if (!n)
         return;
-    const dim3 grid((n + EXPAND_THREADS / 16 - 1) / (EXPAND_THREADS / 16));
-    if (stats && stats_mode == 1)
-        hipLaunchKernelGGL(k_expand<1>, grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
+    const uint32_t nodes = m.ad_mode == 1 ? ExpandShape<1>::NODES : ExpandShape<0>::NODES;
+    const dim3 grid((n + nodes - 1) / nodes);
+    if (m.ad_mode == 1) // the adaptive variants keep no work counters
+        hipLaunchKernelGGL((k_expand<0, 1>), grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
+    else if (m.ad_mode == 2)
+        hipLaunchKernelGGL((k_expand<0, 2>), grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
+    else if (stats && stats_mode == 1)
+        hipLaunchKernelGGL((k_expand<1, 0>), grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
     else
-        hipLaunchKernelGGL(k_expand<0>, grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
+        hipLaunchKernelGGL((k_expand<0, 0>), grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
 }
 
-// kernel<MODE, CURVE> chosen at run time
-#define HYAS_DISPATCH(KERNEL, grid, block, stream, ...)                                                                  \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        const int mode_ = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;                              \
-        const bool rs_ = m.curve_type == HYAS_CURVE_RS, bz_ = m.curve_type == HYAS_CURVE_BEZIER;                       \
-        if (mode_ == 0 && rs_)                                                                                         \
-            hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
-        else if (mode_ == 1 && rs_)                                                                                    \
-            hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
-        else if (mode_ == 2 && rs_)                                                                                    \
-            hipLaunchKernelGGL((KERNEL<2, HYAS_CURVE_RS>), grid, block, 0, stream, __VA_ARGS__);                       \
-        else if (mode_ == 1 && bz_)                                                                                    \
-            hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_BEZIER>), grid, block, 0, stream, __VA_ARGS__);                   \
-        else if (bz_)                                                                                                  \
-            hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_BEZIER>), grid, block, 0, stream, __VA_ARGS__);                   \
-        else if (mode_ == 1)                                                                                           \
-            hipLaunchKernelGGL((KERNEL<1, HYAS_CURVE_DUBINS>), grid, block, 0, stream, __VA_ARGS__);                   \
-        else                                                                                                           \
-            hipLaunchKernelGGL((KERNEL<0, HYAS_CURVE_DUBINS>), grid, block, 0, stream, __VA_ARGS__);                   \
-    } while (0)
+// kernel<MODE, CURVE> chosen at run time: MODE 0 plain, 1 work counters, 2 phase clocks (Reeds-Shepp only)
+template <template <int, int> class Launch, class... Args>
+static void dispatch_mode_curve(const DevMap &m, int mode, Args... args)
+{
+    const bool rs = m.curve_type == HYAS_CURVE_RS, bz = m.curve_type == HYAS_CURVE_BEZIER;
+    if (mode == 0 && rs)
+        Launch<0, HYAS_CURVE_RS>::go(m, args...);
+    else if (mode == 1 && rs)
+        Launch<1, HYAS_CURVE_RS>::go(m, args...);
+    else if (mode == 2 && rs)
+        Launch<2, HYAS_CURVE_RS>::go(m, args...);
+    else if (mode == 1 && bz)
+        Launch<1, HYAS_CURVE_BEZIER>::go(m, args...);
+    else if (bz)
+        Launch<0, HYAS_CURVE_BEZIER>::go(m, args...);
+    else if (mode == 1)
+        Launch<1, HYAS_CURVE_DUBINS>::go(m, args...);
+    else
+        Launch<0, HYAS_CURVE_DUBINS>::go(m, args...);
+}
+
+template <int MODE, int CURVE>
+struct LaunchShot
+{
+    static void go(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap, uint8_t *shot_ok,
+                   float *shot_len, unsigned long long *stats, hipStream_t s)
+    {
+        hipLaunchKernelGGL((k_shot<MODE, CURVE>), dim3(n), dim3(SHOT_THREADS), 0, s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
+    }
+};
+template <int MODE, int CURVE>
+struct LaunchRound
+{
+    template <int ADAPT>
+    static void with(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
+                     uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, hipStream_t s)
+    {
+        constexpr uint32_t nodes = ExpandShape<ADAPT>::NODES;
+        const dim3 grid(n + (n + nodes - 1) / nodes);
+        hipLaunchKernelGGL((k_round<MODE, CURVE, ADAPT>), grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
+                           count, succ, stats);
+    }
+    static void go(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
+                   uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, hipStream_t s)
+    {
+        if constexpr (MODE == 0) // the adaptive variants exist without counters only
+        {
+            if (m.ad_mode == 1)
+                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+            if (m.ad_mode == 2)
+                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+        }
+        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+    }
+};
 
 void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                  uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s)
 {
     if (!n)
         return;
-    HYAS_DISPATCH(k_shot, dim3(n), dim3(SHOT_THREADS), s, m, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats);
+    const int mode = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;
+    dispatch_mode_curve<LaunchShot>(m, mode, in, n, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s);
 }
 
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
@@ -1706,8 +1855,10 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
 {
     if (!n)
         return;
-    const dim3 grid(n + (n + ROUND_THREADS / 16 - 1) / (ROUND_THREADS / 16));
-    HYAS_DISPATCH(k_round, grid, dim3(ROUND_THREADS), s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats);
+    int mode = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;
+    if (m.ad_mode != 0)
+        mode = 0;
+    dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
 }
 
 void launch_shortcut(const DevMap &m, const float *paths, const uint32_t *offs, uint32_t n_paths, uint32_t *out_idx, uint32_t *out_n, hipStream_t s)

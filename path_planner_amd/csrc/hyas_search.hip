@@ -107,6 +107,7 @@ struct Query
 {
     hyas_goal goal;
     SNode start;
+    uint32_t dist_start_goal_bits = 0; // bits of the float GetDistance(start, goal), for the adaptive steering selection
     std::vector<SNode> arena;
     std::vector<HeapItem> heap;
     uint32_t seq = 0;
@@ -377,6 +378,12 @@ struct Driver
             return;
         }
         const SNode pred = q.arena[pid];
+        if (count == 0xFF) // more steering candidates than a node's slots hold (adaptive mode)
+        {
+            q.res.status = HYAS_STATUS_OVERFLOW;
+            q.done = true;
+            return;
+        }
         q.res.successors += count >> 4; // motion-set entries that received a verdict
         count &= 15;
         // the lookups below miss the cache independently of each other: request all their lines first
@@ -601,7 +608,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     HYAS_HIP(c, hipSetDevice(c->device));
     Driver D(c);
     const DevMap &m = c->dm;
-    const int K = m.n_succ;
+    const int K = m.n_slots;
     reset_timers(c);
     c->paths.assign(n, std::vector<float>());
     c->expanded.assign(n, std::vector<int32_t>());
@@ -760,6 +767,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             const float *p = poses + 6 * i;
             q.goal = h_goal[i];
             q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1}; // Node3D(): g = 999, prim = 0
+            {
+                // Utility::GetDistance(start_, goal_), src/collisiondetection.cpp:1389
+                const float d = normf(sub(f2(p[0], p[1]), f2(q.goal.x, q.goal.y)));
+                std::memcpy(&q.dist_start_goal_bits, &d, sizeof d);
+            }
             uint32_t gx, gy;
             bool bad = !pose_ok[2 * i];
             if (!world_to_map(m, p[3], p[4], gx, gy))
@@ -960,7 +972,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             // a node expanded ahead of time always gets its shot evaluated: whether the search will
                             // ask for it is only known when the node is popped
                             const uint32_t shoot = i == 0 ? (q.shoot ? 1u : 0u) : (P_analytic ? 1u : 0u);
-                            stage[qi * KS + i] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, shoot, 0};
+                            stage[qi * KS + i] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, shoot, q.dist_start_goal_bits};
                         }
                     }
                 }

@@ -11,6 +11,7 @@
 #include "../../path_planner_amd/csrc/hyas_rs.h"
 #include "../../path_planner_amd/csrc/hyas_flood.h"
 #include "../../path_planner_amd/csrc/hyas_bezier.h"
+#include "../../path_planner_amd/csrc/hyas_adaptive.h"
 #include <queue>
 
 using namespace hyas;
@@ -313,4 +314,72 @@ extern "C" float hg_bezier_eval(const float *start, const float *goal, float t, 
     bz::value(c, pw, out4[0], out4[1]);
     bz::angle_curvature(c, pw, out4[2], out4[3]);
     return len;
+}
+
+// ---- adaptive step size / steering, the shared header run on the host --------------------------------------------
+extern "C" float hg_ray_distance(const float *quad8, float px, float py, float angle)
+{
+    Quad q{};
+    for (int i = 0; i < 4; ++i)
+        q.vx[i] = quad8[2 * i], q.vy[i] = quad8[2 * i + 1];
+    return ad::ray_distance(q, f2(px, py), angle);
+}
+extern "C" int hg_sweep_angles(float *out, int cap)
+{
+    const std::vector<float> a = ad::sweep_angles();
+    for (int i = 0; i < (int)a.size() && i < cap; ++i)
+        out[i] = a[i];
+    return (int)a.size();
+}
+// run-length pass + cut to the circle for one cell; out3: {label, start, width} triples
+extern "C" int hg_ranges_of_sweep(const float *angle, const float *dist, int n, float min_distance, float detection_range, int cut, float *out3, int cap)
+{
+    std::vector<ad::Range> v;
+    ad::ranges_of_sweep(angle, dist, (size_t)n, min_distance, detection_range, v);
+    if (cut)
+        ad::cut_to_circle(v);
+    for (int i = 0; i < (int)v.size() && i < cap; ++i)
+        out3[3 * i] = v[i].dist, out3[3 * i + 1] = v[i].start, out3[3 * i + 2] = v[i].range;
+    return (int)v.size();
+}
+// The pair list of n nodes over a map given by its per-key ranges (CSR) and densities.
+// flags: bit 0 add_one_more, 1 only in free ranges, 2 towards free range, 3 fixed number; steer/n_steer: the forward
+// steering set.  pairs2: n x 13 x {step, steer}; counts[i] = pairs of node i, -1 on overflow.
+extern "C" void hg_step_steer_pairs(int w, int h, double res, double ox, double oy, const uint32_t *ad_off, const float *ad_rng, const float *ad_density,
+                                    float detection_range, float constant_density, int mode, int flags, const float *steer, int n_steer,
+                                    const float *nodes_xyt, const float *goals_xyt, const float *dist_start_goal, int n, float *pairs2, int *counts)
+{
+    DevMap m{};
+    m.w = w, m.h = h, m.res = res, m.ox = ox, m.oy = oy, m.res_f = (float)res, m.ox_f = (float)ox, m.oy_f = (float)oy;
+    int e = 0;
+    const bool p2 = std::frexp(res, &e) == 0.5 && (double)m.res_f == res;
+    m.res_pow2 = p2, m.inv_res = p2 ? 1.0 / res : 0, m.inv_res_f = p2 ? (float)(1.0 / res) : 0;
+    m.ad_off = ad_off, m.ad_rng = ad_rng, m.ad_density = ad_density, m.ad_range = detection_range, m.ad_constant_density = constant_density;
+    m.ad_mode = mode, m.ad_one_more = flags & 1, m.ad_one_more_free_only = (flags >> 1) & 1, m.ad_towards_free = (flags >> 2) & 1,
+    m.ad_fixed_number = (flags >> 3) & 1;
+    m.n_succ = n_steer;
+    for (int k = 0; k < n_steer; ++k)
+        m.succ_steer[k] = steer[k], m.succ_reverse[k] = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        float st[HYAS_AD_MAX_PAIRS], sa[HYAS_AD_MAX_PAIRS];
+        ad::Pairs p;
+        p.step = st, p.steer = sa;
+        ad::step_steer_pairs(m, nodes_xyt[3 * i], nodes_xyt[3 * i + 1], nodes_xyt[3 * i + 2], goals_xyt[3 * i], goals_xyt[3 * i + 1], goals_xyt[3 * i + 2],
+                             dist_start_goal[i], p);
+        counts[i] = p.overflow ? -1 : p.n;
+        for (int k = 0; k < p.n; ++k)
+            pairs2[(i * HYAS_AD_MAX_PAIRS + k) * 2] = st[k], pairs2[(i * HYAS_AD_MAX_PAIRS + k) * 2 + 1] = sa[k];
+    }
+}
+
+extern "C" int hg_cut_to_circle(const float *in3, int n, float *out3)
+{
+    std::vector<ad::Range> v(n);
+    for (int i = 0; i < n; ++i)
+        v[i] = ad::Range{in3[3 * i], in3[3 * i + 1], in3[3 * i + 2]};
+    ad::cut_to_circle(v);
+    for (size_t i = 0; i < v.size(); ++i)
+        out3[3 * i] = v[i].dist, out3[3 * i + 1] = v[i].start, out3[3 * i + 2] = v[i].range;
+    return (int)v.size();
 }

@@ -82,7 +82,7 @@ def default_params(**kw):
     p = Params(
         position_resolution=10, headings=72, cd_min_turning_radius=6.0, curve_type=0, vehicle_width=1.0,
         vehicle_length=2.0, obstacle_detection_range=5.0, map_boundary_obstacle=0, number_of_successors=3,
-        adaptive_steering_angle_and_step_size=0, adaptive_step_size=0, analytical_expansion_every_point=1,
+        adaptive_steering_angle_and_step_size=0, adaptive_step_size=1, analytical_expansion_every_point=1,
         analytical_expansion=1, penalty_turning=1.05, penalty_reverse=1.0, penalty_change_of_direction=2.0,
         reverse=0, max_iterations=10000, steering_angle=5.0, goal_range=1e-3, tie_breaker=0.01,
         min_turning_radius=6.0, fp_width=0.18, fp_length=0.22, fp_cell_size=1.0, short_cut=1, max_steering_angle=30.0,
@@ -100,7 +100,7 @@ def default_params(**kw):
 def hot_path_params(**kw):
     """Fixed-step Reeds-Shepp configuration the benchmarks are quoted on."""
     base = dict(curve_type=1, number_of_successors=5, steering_angle=5.0, reverse=1,
-                analytical_expansion=1, analytical_expansion_every_point=1, short_cut=0)
+                analytical_expansion=1, analytical_expansion_every_point=1, short_cut=0, adaptive_step_size=0)
     base.update(kw)
     return default_params(**base)
 
@@ -136,7 +136,8 @@ class Oracle:
                   "orc_table_lookup", "orc_plan", "orc_get_path", "orc_get_expanded", "orc_footprint_table",
                   "orc_get_obstacles", "orc_in_range_count", "orc_num_obstacles", "orc_num_successors",
                   "orc_table_dims", "orc_build_table", "orc_rs_path", "orc_rs_sample", "orc_dubins",
-                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid", "orc_plan_r", "orc_shortcut"):
+                  "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid", "orc_plan_r", "orc_shortcut", "orc_expand_batch_from",
+                  "orc_step_steer_pairs", "orc_adaptive_cell"):
             getattr(L, f).argtypes = None
         self.params = params
         self.h = C.c_void_p(L.orc_create(C.byref(params)))
@@ -190,20 +191,44 @@ class Oracle:
     def num_successors(self):
         return self.L.orc_num_successors(self.h)
 
-    def expand(self, preds, goals, twod=None):
+    def expand(self, preds, goals, twod=None, starts=None):
         preds = np.ascontiguousarray(preds, NODE_DT)
         goals = np.ascontiguousarray(goals, GOAL_DT)
         n = preds.shape[0]
         K = self.num_successors()
         out = np.zeros((n, K), SUCC_DT)
         cnt = np.zeros(n, np.uint8)
-        tp = None
+        tp = sp = None
         if twod is not None:
             twod = np.ascontiguousarray(twod, np.float32)
             tp = twod.ctypes.data_as(C.c_void_p)
-        self.L.orc_expand_batch(self.h, preds.ctypes.data_as(C.c_void_p), goals.ctypes.data_as(C.c_void_p), tp,
-                                C.c_size_t(n), out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+        if starts is not None:
+            starts = np.ascontiguousarray(starts, GOAL_DT)
+            sp = starts.ctypes.data_as(C.c_void_p)
+        self.L.orc_expand_batch_from(self.h, preds.ctypes.data_as(C.c_void_p), goals.ctypes.data_as(C.c_void_p), sp, tp,
+                                     C.c_size_t(n), out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
         return out, cnt
+
+    def step_steer_pairs(self, pred, goal, start, cap=64):
+        """{step size, steering angle} pairs of one node (reverse pair included), as CreateSuccessor forms them."""
+        a, g, s = np.zeros(1, NODE_DT), np.zeros(1, GOAL_DT), np.zeros(1, GOAL_DT)
+        a["x"], a["y"], a["t"] = pred
+        g["x"], g["y"], g["t"] = goal
+        s["x"], s["y"], s["t"] = start
+        out = np.zeros((cap, 2), np.float32)
+        n = self.L.orc_step_steer_pairs(self.h, a.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                                        s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), cap)
+        return out[:min(n, cap)], n
+
+    def adaptive_cell(self, key, cap=256, cut=False):
+        """(min distance, normalised density, [(distance, start, range)...]) of one grid cell, or None; cut: the ranges
+        as FindFreeAngleRangeAndObstacleAngleRange hands them on (cut to the circle less 0.0001 degrees)."""
+        md, de = C.c_float(), C.c_float()
+        r = np.zeros((cap, 3), np.float32)
+        n = self.L.orc_adaptive_cell(self.h, C.c_uint32(key), C.byref(md), C.byref(de), r.ctypes.data_as(C.c_void_p), cap, int(cut))
+        if n < 0:
+            return None
+        return md.value, de.value, r[:n].copy()
 
     def shot(self, nodes, goals):
         nodes = np.ascontiguousarray(nodes, NODE_DT)

@@ -1,0 +1,124 @@
+"""GPU parity of the adaptive step-size / steering modes (HybridAStar::CreateSuccessor, src/hybrid_a_star.cpp:547-599,
+with CollisionDetection::FindStepSizeAndSteeringAngle / FindStepSize and the maps built per costmap,
+src/collisiondetection.cpp:387-500, :688-938, :1013-1151, :1263-1484) against the CPU oracle, bit for bit."""
+import math
+
+import numpy as np
+import pytest
+
+import orc
+from path_planner_amd import _lib as hl
+from test_gpu_parity import Pair, _nodes, _plan_compare
+
+pytestmark = pytest.mark.gpu
+
+COMBINED = dict(adaptive_steering_angle_and_step_size=1)
+STEP_ONLY = dict(adaptive_step_size=1)
+
+
+@pytest.fixture(scope="module")
+def maze_combined(oracle_built):
+    return Pair("map_maze", position_resolution=2, max_iterations=400, **COMBINED)
+
+
+@pytest.fixture(scope="module")
+def parking_step(oracle_built):
+    return Pair("map_parking", position_resolution=2, max_iterations=400, **STEP_ONLY)
+
+
+@pytest.mark.parametrize("name,res,ox,oy", [("map_maze", 1.0, 0.0, 0.0), ("map_parking", 1.0, 0.0, 0.0), ("map_large", 1.0, 0.0, 0.0),
+                                            ("map_basic", 0.5, -3.25, 2.5)])
+def test_adaptive_maps(oracle_built, name, res, ox, oy):
+    """Minimum obstacle distance, normalised density and the angle ranges of every grid key."""
+    p = Pair(name, res=res, ox=ox, oy=oy, position_resolution=1, **COMBINED)
+    seen = 0
+    for key in range(p.W * p.H):
+        want = p.o.adaptive_cell(key, cut=True)
+        md, de, rng = p.h.adaptive_cell(key)
+        if want is None:
+            assert len(rng) == 0 and de == 0
+            continue
+        seen += 1
+        assert np.float32(want[0]).view(np.uint32) == np.float32(md).view(np.uint32), key
+        assert np.float32(want[1]).view(np.uint32) == np.float32(de).view(np.uint32), key
+        assert want[2].tobytes() == rng.tobytes(), (key, want[2], rng)
+    assert seen >= p.W * p.H - 1
+
+
+def _starts(p, n, seed):
+    s = np.zeros(n, orc.GOAL_DT)
+    xyt = p.free_poses(n, seed)
+    s["x"], s["y"], s["t"] = xyt[:, 0], xyt[:, 1], xyt[:, 2]
+    return s
+
+
+@pytest.mark.parametrize("flags", [0b1101, 0b0000, 0b0111, 0b1010, 0b0101])
+def test_expand_combined_mode(oracle_built, flags):
+    """Successors with adaptive steering angle and step size; flags: add one more successor, only in free ranges,
+    steer towards the free range, fixed number of steering angles in a free range (0b1101: the reference's defaults)."""
+    kw = dict(add_one_more_successor=flags & 1, add_one_more_successor_only_in_free_angle_range=(flags >> 1) & 1,
+              steering_angle_towards_free_angle_range_for_obstacle_angle_range=(flags >> 2) & 1,
+              fixed_number_of_steering_angle_in_free_angle_range=(flags >> 3) & 1)
+    p = Pair("map_maze", position_resolution=1, **COMBINED, **kw)
+    assert p.h.num_successors() == 16 == p.o.num_successors()
+    nodes, goals = _nodes(p, 3000, 40 + flags)
+    starts = _starts(p, 3000, 90 + flags)
+    # more than 13 forward candidates do not fit a node's slots: flagged, never silently cut (the reference's default
+    # switches stay far below that; the 5-degree fans of fixed_number... = 0 can exceed it)
+    over = np.array([p.o.step_steer_pairs((nd["x"], nd["y"], nd["t"]), (g["x"], g["y"], g["t"]), (s["x"], s["y"], s["t"]))[1] - 1 > 13
+                     for nd, g, s in zip(nodes, goals, starts)])
+    if flags == 0b1101:
+        assert not over.any()
+    fits = np.flatnonzero(~over)[:48]
+    twod = np.stack([p.o.flood((g["x"], g["y"], g["t"])) for g in goals[fits]])
+    a, ca = p.o.expand(nodes[fits], goals[fits], twod, starts[fits])
+    b, cb = p.h.expand(nodes[fits], goals[fits], twod, starts[fits])
+    assert np.array_equal(ca, cb) and a.tobytes() == b.tobytes()
+    a, ca = p.o.expand(nodes, goals, None, starts)
+    b, cb = p.h.expand(nodes, goals, None, starts)
+    assert np.array_equal(cb[over], np.full(over.sum(), 0xFF, np.uint8))
+    assert np.array_equal(ca[~over], cb[~over])
+    assert a[~over].tobytes() == b[~over].tobytes()
+    assert ca.max() >= 3 and (ca == 0).sum() < len(ca) // 2
+    # the plain entry point has no start pose to weigh with
+    with pytest.raises(hl.HyasError):
+        p.h.expand(nodes[:4], goals[:4])
+
+
+def test_expand_step_only_mode(parking_step, oracle_built):
+    for p, seed in ((parking_step, 51), (Pair("map_maze", position_resolution=1, reverse=0, number_of_successors=7, **STEP_ONLY), 52)):
+        nodes, goals = _nodes(p, 3000, seed)
+        a, ca = p.o.expand(nodes, goals)
+        b, cb = p.h.expand(nodes, goals)
+        assert np.array_equal(ca, cb)
+        assert a.tobytes() == b.tobytes()
+        step = np.hypot(a["x"][:, 0] - nodes["x"], a["y"][:, 0] - nodes["y"])[ca > 0]
+        assert step.max() > 1.0  # steps longer than the fixed 0.2
+
+
+def test_plan_adaptive_modes(maze_combined, parking_step, oracle_built):
+    """Whole searches: result record, expanded nodes in order and path, both modes, three maps."""
+    large = Pair("map_large", position_resolution=1, max_iterations=300, **COMBINED)
+    for p, seed, n in ((maze_combined, 71, 48), (parking_step, 72, 32), (large, 73, 32)):
+        s, g = p.free_poses(n, seed), p.free_poses(n, seed + 1)
+        res = _plan_compare(p, s, g)
+        assert len(set(res["status"].tolist())) >= 2
+
+
+def test_reference_defaults_plan(oracle_built):
+    """The reference's struct defaults (adaptive_step_size = true, Dubins, three successors, short_cut) end to end."""
+    po = orc.default_params(position_resolution=2, max_iterations=300)
+    assert po.adaptive_step_size == 1 and hl.default_params().adaptive_step_size == 1
+    p = Pair.__new__(Pair)
+    ph = hl.Params()
+    for name, _ in hl.Params._fields_:
+        setattr(ph, name, getattr(po, name))
+    p.map = orc.load_map("map_maze")
+    p.o = orc.Oracle(po)
+    p.o.set_costmap(p.map, build_table=True, nthreads=16)
+    p.h = hl.Hyas(ph)
+    p.h.set_costmap(p.map, build_table=True)
+    p.H, p.W = p.map.shape
+    p.res, p.ox, p.oy = 1.0, 0.0, 0.0
+    s, g = p.free_poses(32, 75), p.free_poses(32, 76)
+    _plan_compare(p, s, g)

@@ -24,7 +24,7 @@ def host_geom():
     so, src = HG / "libhost_geom.so", HG / "host_geom.cpp"
     deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h",
             ROOT / "path_planner_amd/csrc/hyas_rs.h", ROOT / "path_planner_amd/csrc/hyas_flood.h",
-            ROOT / "path_planner_amd/csrc/hyas_bezier.h"]
+            ROOT / "path_planner_amd/csrc/hyas_bezier.h", ROOT / "path_planner_amd/csrc/hyas_adaptive.h"]
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
                         "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
@@ -192,3 +192,72 @@ def test_bezier_header_equals_oracle(host_geom, oracle_built):
         lb = host_geom.hg_bezier_eval(vp(s), vp(g), t, vp(ob))
         assert np.float32(la).view(np.uint32) == np.float32(lb).view(np.uint32)
         assert oa[[0, 1, 3, 4]].tobytes() == ob.tobytes(), (s, g, t, oa, ob)
+
+
+def test_adaptive_header_equals_oracle(host_geom, oracle_built):
+    """The adaptive step-size / steering header (angle-range algebra, ray distance, pair selection), run on the host,
+    against the oracle's restatement of src/collisiondetection.cpp:688-938, :1263-1484 and src/utility.cpp: same bits."""
+    vp = lambda v: v.ctypes.data_as(C.c_void_p)
+    o0 = orc.Oracle(orc.hot_path_params())
+    host_geom.hg_ray_distance.restype = C.c_float
+    host_geom.hg_ray_distance.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    rng = np.random.default_rng(21)
+    for k in range(20000):
+        ox, oy = float(rng.integers(0, 20)), float(rng.integers(0, 20))
+        wd, ht = 1.0, float(rng.integers(1, 6))
+        px, py = (float(rng.integers(0, 25)), float(rng.integers(0, 25))) if k % 3 else (float(rng.uniform(0, 25)), float(rng.uniform(0, 25)))
+        ang = float(np.float32(rng.integers(0, 361) * np.float32(math.pi / 180))) if k % 2 else float(rng.uniform(0, 6.4))
+        quad = np.array([ox, oy, ox + wd, oy, ox + wd, oy + ht, ox, oy + ht], np.float32)
+        a = o0.utility(29, [ox, oy, px, py, ang, wd, ht])
+        b = host_geom.hg_ray_distance(vp(quad), px, py, ang)
+        assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (ox, oy, ht, px, py, ang, a, b)
+    # pair selection over the oracle's own maps, every combination of the four switches on one map, defaults on two
+    cases = [("map_maze", m, f) for m in (1, 2) for f in range(16)] + [("map_parking", 1, 0b1101), ("map_large", 1, 0b1101)]
+    for name, mode, flags in cases:
+        if mode == 2 and flags != 0b1101:
+            continue
+        kw = dict(add_one_more_successor=flags & 1, add_one_more_successor_only_in_free_angle_range=(flags >> 1) & 1,
+                  steering_angle_towards_free_angle_range_for_obstacle_angle_range=(flags >> 2) & 1,
+                  fixed_number_of_steering_angle_in_free_angle_range=(flags >> 3) & 1)
+        kw["adaptive_steering_angle_and_step_size" if mode == 1 else "adaptive_step_size"] = 1
+        p = orc.hot_path_params(position_resolution=1, **kw)
+        o = orc.Oracle(p)
+        grid = orc.load_map(name)
+        o.set_costmap(grid, build_table=False)
+        H, W = grid.shape
+        off, rngs, dens = [0], [], np.zeros(W * H, np.float32)
+        for key in range(W * H):
+            c = o.adaptive_cell(key)
+            if c is not None:
+                raw = np.ascontiguousarray(c[2], np.float32)
+                out = np.zeros((max(len(raw), 1), 3), np.float32)
+                n = host_geom.hg_cut_to_circle(vp(raw), len(raw), vp(out))
+                rngs.append(out[:n])
+                dens[key] = c[1]
+            off.append(off[-1] + (len(rngs[-1]) if c is not None else 0))
+        off = np.array(off, np.uint32)
+        rr = np.ascontiguousarray(np.concatenate(rngs), np.float32)
+        n = 4000
+        nodes = np.stack([rng.uniform(0.5, W - 0.5, n), rng.uniform(0.5, H - 0.5, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
+        goals = np.stack([rng.uniform(0.5, W - 0.5, n), rng.uniform(0.5, H - 0.5, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
+        starts = np.stack([rng.uniform(0.5, W - 0.5, n), rng.uniform(0.5, H - 0.5, n), rng.uniform(0, 2 * math.pi, n)], 1).astype(np.float32)
+        goals[:200, :2] = nodes[:200, :2] + rng.uniform(-0.5, 0.5, (200, 2)).astype(np.float32)  # goal within one step
+        nodes[200:400, :2] = np.round(nodes[200:400, :2])  # nodes on cell corners
+        dsg = np.sqrt(((starts[:, 0] - goals[:, 0]) ** 2 + (starts[:, 1] - goals[:, 1]) ** 2).astype(np.float32)).astype(np.float32)
+        d = np.float32(o0.utility(17, [p.steering_angle]))  # ConvertDegToRad(steering_angle)
+        steer = np.array([0] + [np.float32(s) * (np.float32(i) * d) for i in range(1, (p.number_of_successors - 1) // 2 + 1) for s in (1, -1)], np.float32)
+        pairs = np.zeros((n, 13, 2), np.float32)
+        counts = np.zeros(n, np.int32)
+        host_geom.hg_step_steer_pairs(W, H, C.c_double(1.0), C.c_double(0.0), C.c_double(0.0), vp(off), vp(rr), vp(dens), C.c_float(p.obstacle_detection_range),
+                                      C.c_float(p.constant_density), mode, flags, vp(steer), len(steer), vp(nodes), vp(goals), vp(dsg), n, vp(pairs), vp(counts))
+        most = 0
+        for i in range(n):
+            want, nw = o.step_steer_pairs(nodes[i], goals[i], starts[i])
+            want, nw = want[:nw - 1], nw - 1  # the reverse pair comes from the fixed rule
+            if nw > 13:
+                assert counts[i] == -1
+                continue
+            assert counts[i] == nw, (name, mode, flags, i, counts[i], nw)
+            assert pairs[i, :nw].tobytes() == want.tobytes(), (name, mode, flags, i, pairs[i, :nw], want)
+            most = max(most, nw)
+        assert most >= 3
