@@ -2496,6 +2496,51 @@ struct Ctx
     {
         return (std::abs(a.x - b.x) < 1e-2) && (std::abs(a.y - b.y) < 1e-2) && (std::abs(a.t - b.t) < 1e-2);
     }
+    // CubicBezier::ConvertCubicBezierToVector3f (src/cubic_bezier.cpp:179-194) appended to out as nodes
+    // (Utility::TypeConversion(Vector3f, Node3D), src/utility.cpp:128-133)
+    static void appendBezierNodes(const bez::Cubic &c, unsigned number_of_points, std::vector<Node3D> &out)
+    {
+        for (unsigned i = 0; i < number_of_points + 1; ++i)
+        {
+            const float t = (float)i / number_of_points;
+            float v[3];
+            c.GetValueAt(t, v);
+            Node3D nd;
+            nd.x = v[0], nd.y = v[1], nd.t = RadToZeroTo2P(RadToZeroTo2P(c.GetAngleAt(t)));
+            out.push_back(nd);
+        }
+    }
+    // HybridAStar::ConvertToPiecewiseCubicBezierPath (src/hybrid_a_star.cpp:830-883) with PiecewiseCubicBezier::
+    // SetAnchorPoints / CalculateCubicBezier / ConvertPiecewiseCubicBezierToVector3f (include/piecewise_cubic_bezier.h:51-60,
+    // src/piecewise_cubic_bezier.cpp:221-234, :336-357): one cubic Bezier curve between consecutive anchor points, the
+    // traced nodes at least one cell apart up to the node the analytic curve starts from.  CalculateCubicBezier counts
+    // to size() - 1 in unsigned arithmetic: an empty anchor list is undefined there and gives no curve here.
+    std::vector<Node3D> ConvertToPiecewiseCubicBezierPath(const std::vector<Node3D> &path_, size_t analytical_expansion_index_, const Node3D &start_) const
+    {
+        std::vector<Node3D> anchor_points_vec, out;
+        Node3D end_point;
+        end_point.x = 0, end_point.y = 0, end_point.t = 0;
+        for (unsigned index = 0; index < path_.size() - 1; ++index)
+        {
+            if (index == analytical_expansion_index_)
+            {
+                end_point.x = path_[index].x, end_point.y = path_[index].y, end_point.t = RadToZeroTo2P(path_[index].t);
+                anchor_points_vec.push_back(path_[index]);
+                break;
+            }
+            if (GetDistance(path_[index], path_[index + 1]) < resolution_)
+                continue;
+            anchor_points_vec.push_back(path_[index]);
+        }
+        const int number_of_points = (int)m_roundf(GetDistance(start_, end_point) / resolution_);
+        for (size_t i = 0; i + 1 < anchor_points_vec.size(); ++i)
+        {
+            const float a[3] = {anchor_points_vec[i].x, anchor_points_vec[i].y, anchor_points_vec[i].t};
+            const float b[3] = {anchor_points_vec[i + 1].x, anchor_points_vec[i + 1].y, anchor_points_vec[i + 1].t};
+            appendBezierNodes(bez::Cubic(a, b), (unsigned)number_of_points, out);
+        }
+        return out;
+    }
     // src/utility.cpp:2091-2109
     void RemoveDuplicates(std::vector<Node3D> &path) const
     {
@@ -2670,8 +2715,17 @@ struct Ctx
                 {
                     trace(pid);
                     shortcut(); // :165-168, before the curve is appended
+                    const size_t analytical_expansion_index = path.size(); // :169, :212
                     path.insert(path.end(), shot.begin(), shot.end());
                     res->shot_length = slen;
+                    if (P.piecewise_cubic_bezier_interpolation) // :178-189, :218-229
+                    {
+                        if (P.analytical_expansion_every_point)
+                            RemoveDuplicates(path); // :172 comes before the conversion, :230 after the return
+                        std::vector<Node3D> pw = ConvertToPiecewiseCubicBezierPath(path, analytical_expansion_index, start);
+                        pw.insert(pw.end(), shot.begin(), shot.end());
+                        path.swap(pw); // RemoveDuplicates of :184 / :224 and of :994 follow in finish()
+                    }
                     finish(HYAS_STATUS_SHOT, pid);
                     return;
                 }

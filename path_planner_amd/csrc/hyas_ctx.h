@@ -123,6 +123,8 @@ int ensure_nodes(hyas_ctx *c, size_t bytes);
 int ensure_buffer(hyas_ctx *c, void **buf, size_t *have, size_t bytes); // device buffer that only grows
 void free_search_pools(hyas_ctx *c);
 // HybridAStar::ShortCut for n paths on the GPU (host pointers; layout as launch_shortcut); synchronous on c->stream
+int bezier_points(hyas_ctx *c, const float *anchors, size_t n_anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, size_t n_curves,
+                  size_t total_points, float *out);
 int shortcut_paths(hyas_ctx *c, const float *paths, const uint32_t *offs, size_t n, uint32_t *out_idx, uint32_t *out_n);
 // 2D flood of `nq` queries on the GPU (see k_flood): poses6_dev / qlist_dev / twod_dev / start_cost_dev are device
 // pointers; launches on `s` and returns without waiting

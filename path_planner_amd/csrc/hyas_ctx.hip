@@ -129,6 +129,33 @@ int shortcut_paths(hyas_ctx *c, const float *paths, const uint32_t *offs, size_t
     return HYAS_OK;
 }
 
+// Samples of n_curves cubic Bezier curves between consecutive anchor poses (k_bezier_points): anchors = n_anchors x
+// {x, y, heading}, curve c from anchor first[c]; out receives the poses of curve c at off[c].
+int bezier_points(hyas_ctx *c, const float *anchors, size_t n_anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, size_t n_curves,
+                  size_t total_points, float *out)
+{
+    if (!n_curves || !total_points)
+        return HYAS_OK;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_anc = 0, o_first = up(n_anchors * 3 * sizeof(float)), o_off = o_first + up(n_curves * sizeof(uint32_t)),
+                 o_n = o_off + up(n_curves * sizeof(uint32_t)), o_out = o_n + up(n_curves * sizeof(uint32_t)),
+                 bytes = o_out + up(total_points * 3 * sizeof(float));
+    int rc = ensure_buffer(c, &c->d_sc, &c->d_sc_bytes, bytes);
+    if (rc != HYAS_OK)
+        return rc;
+    char *d = (char *)c->d_sc;
+    HYAS_HIP(c, hipMemcpyAsync(d + o_anc, anchors, n_anchors * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HYAS_HIP(c, hipMemcpyAsync(d + o_first, first, n_curves * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HYAS_HIP(c, hipMemcpyAsync(d + o_off, off, n_curves * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HYAS_HIP(c, hipMemcpyAsync(d + o_n, n, n_curves * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    launch_bezier_points((const float *)(d + o_anc), (const uint32_t *)(d + o_first), (const uint32_t *)(d + o_off), (const uint32_t *)(d + o_n),
+                         (uint32_t)n_curves, (float *)(d + o_out), c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipMemcpyAsync(out, d + o_out, total_points * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    return HYAS_OK;
+}
+
 // Device memory for the round kernel's input that the host writes with plain stores: fine-grained (coherent)
 // device memory on a GPU whose whole memory is visible to the CPU.  The kernel then reads its node from local
 // memory (0.5 us) instead of fetching it from host memory over PCIe (1.5-2 us).  Leaves d_nodes null where that
@@ -584,8 +611,6 @@ static bool params_ok(const hyas_params *p, std::string &why)
         why = "the adaptive modes need a positive obstacle_detection_range";
     else if (p->map_boundary_obstacle)
         why = "map_boundary_obstacle is not supported";
-    else if (p->piecewise_cubic_bezier_interpolation)
-        why = "piecewise_cubic_bezier_interpolation is not supported";
     else if (p->headings < 1 || p->headings > 720 || p->position_resolution < 1 || p->position_resolution > 64)
         why = "headings / position_resolution out of range";
     else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS && p->curve_type != HYAS_CURVE_BEZIER)

@@ -40,6 +40,7 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
                   int stats_mode, hipStream_t s);
 // paths: concatenated poses {x, y, t}; offs: n_paths + 1 pose offsets; out_idx: offs[n_paths] + n_paths entries; out_n: n_paths
+void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s);
 void launch_shortcut(const DevMap &m, const float *paths, const uint32_t *offs, uint32_t n_paths, uint32_t *out_idx, uint32_t *out_n, hipStream_t s);
 void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                       const uint32_t *offsets, float *out, uint32_t *n_out, hipStream_t s);

@@ -1365,6 +1365,29 @@ __global__ void __launch_bounds__(256) k_shot_path(DevMap m, const StepIn *__res
     }
 }
 
+// Piecewise cubic Bezier interpolation of traced paths (PiecewiseCubicBezier::ConvertPiecewiseCubicBezierToVector3f,
+// src/piecewise_cubic_bezier.cpp:336-357, over CubicBezier::ConvertCubicBezierToVector3f, src/cubic_bezier.cpp:179-194):
+// curve c runs from anchor first[c] to the anchor behind it and is sampled at i / n[c], i = 0 .. n[c]; its n[c] + 1
+// poses {x, y, heading} start at out + 3 * off[c].  One workgroup per curve.
+__global__ void __launch_bounds__(64) k_bezier_points(const float *__restrict__ anchors, const uint32_t *__restrict__ first, const uint32_t *__restrict__ off,
+                                                      const uint32_t *__restrict__ n, float *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x, np = n[c];
+    const float *a = anchors + 3 * (size_t)first[c];
+    const float s[3] = {a[0], a[1], a[2]}, g[3] = {a[3], a[4], a[5]};
+    const bz::Curve curve = bz::make(s, g);
+    float *dst = out + 3 * (size_t)off[c];
+    for (uint32_t i = threadIdx.x; i < np + 1; i += blockDim.x)
+    {
+        const bz::Powers pw = bz::powers((float)i / (float)np);
+        float x, y, angle, curvature;
+        bz::value(curve, pw, x, y);
+        bz::angle_curvature(curve, pw, angle, curvature);
+        // the heading is normalised by the curve and once more by the conversion to a node (src/utility.cpp:128-133)
+        dst[3 * i] = x, dst[3 * i + 1] = y, dst[3 * i + 2] = rad_0_2pi(rad_0_2pi(angle));
+    }
+}
+
 // -------------------------------------------------------------- path shortcut
 // HybridAStar::ShortCut(path, true) (src/hybrid_a_star.cpp:1076-1179), one path per workgroup.  From the path's last
 // node the reference walks towards its first for as long as CollisionDetection::IsTraversable(current, node)
@@ -1859,6 +1882,12 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
     if (m.ad_mode != 0)
         mode = 0;
     dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+}
+
+void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s)
+{
+    if (n_curves)
+        hipLaunchKernelGGL(k_bezier_points, dim3(n_curves), dim3(64), 0, s, anchors, first, off, n, out);
 }
 
 void launch_shortcut(const DevMap &m, const float *paths, const uint32_t *offs, uint32_t n_paths, uint32_t *out_idx, uint32_t *out_n, hipStream_t s)

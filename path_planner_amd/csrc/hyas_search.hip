@@ -290,6 +290,31 @@ struct Driver
             }
         }
     }
+    // The anchor poses of HybridAStar::ConvertToPiecewiseCubicBezierPath (src/hybrid_a_star.cpp:839-862): path nodes at
+    // least one cell from their successor, up to and including the node the analytic curve starts from.  Returns the
+    // sample count per curve, round(distance(start, that node) / resolution) (:873); the node stays (0, 0, 0) when the
+    // loop never reaches its index.  Fewer than two anchors: no curve (the reference counts to size() - 1 unsigned).
+    uint32_t piecewise_anchors(const Query &q, size_t analytical_expansion_index, std::vector<float> &anchors) const
+    {
+        anchors.clear();
+        const std::vector<float> &p = q.path;
+        const size_t n = p.size() / 3;
+        float ex = 0, ey = 0;
+        for (uint32_t index = 0; index < n - 1; ++index)
+        {
+            if (index == analytical_expansion_index)
+            {
+                ex = p[3 * index], ey = p[3 * index + 1];
+                anchors.insert(anchors.end(), p.begin() + 3 * index, p.begin() + 3 * index + 3);
+                break;
+            }
+            if (normf(sub(f2(p[3 * index], p[3 * index + 1]), f2(p[3 * index + 3], p[3 * index + 4]))) < m.res_f)
+                continue;
+            anchors.insert(anchors.end(), p.begin() + 3 * index, p.begin() + 3 * index + 3);
+        }
+        const int number_of_points = (int)hy_roundf(normf(sub(f2(q.start.x, q.start.y), f2(ex, ey))) / m.res_f);
+        return (uint32_t)number_of_points;
+    }
     // n_rd: how many RemoveDuplicates passes are still due (GetPath's own, unless the caller has run it in front of
     // ShortCut, and calculatePath's, :994)
     void finish(Query &q, int status, int32_t id, int n_rd) const
@@ -1189,15 +1214,58 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess)
                     return hip_fail(c, e, "shot path download");
+                const bool piecewise = c->P.piecewise_cubic_bezier_interpolation != 0;
+                // piecewise interpolation (:178-189, :218-229): per query the anchor poses and the sample count
+                std::vector<std::vector<float>> anchors(piecewise ? nsq : 0);
+                std::vector<uint32_t> pw_n(piecewise ? nsq : 0);
                 pool.run(nsq, [&](size_t a, size_t b) {
                     for (size_t k = a; k < b; ++k)
                     {
                         Query &q = Q[shot_q[k]];
+                        const size_t analytical_expansion_index = q.path.size() / 3; // :169, :212
                         q.path.insert(q.path.end(), shot_buf.begin() + 3 * (size_t)h_off[k], shot_buf.begin() + 3 * ((size_t)h_off[k] + h_cnt[k]));
                         q.path.push_back(q.goal.x), q.path.push_back(q.goal.y), q.path.push_back(q.goal.t);
-                        D.finish(q, HYAS_STATUS_SHOT, q.shot_from, 2);
+                        if (!piecewise)
+                        {
+                            D.finish(q, HYAS_STATUS_SHOT, q.shot_from, 2);
+                            continue;
+                        }
+                        if (c->P.analytical_expansion_every_point)
+                            Driver::remove_duplicates(q.path); // :172 runs before the conversion, :230 after the return
+                        pw_n[k] = D.piecewise_anchors(q, analytical_expansion_index, anchors[k]);
                     }
                 });
+                if (piecewise)
+                {
+                    // every curve of every query in one launch: curve j of query k runs between its anchors j and j + 1
+                    std::vector<float> anc;
+                    std::vector<uint32_t> first, off, cnt, q_off(nsq + 1, 0);
+                    size_t total_pts = 0;
+                    for (size_t k = 0; k < nsq; ++k)
+                    {
+                        const size_t na = anchors[k].size() / 3, base_anchor = anc.size() / 3;
+                        anc.insert(anc.end(), anchors[k].begin(), anchors[k].end());
+                        for (size_t j = 0; j + 1 < na; ++j)
+                            first.push_back((uint32_t)(base_anchor + j)), off.push_back((uint32_t)total_pts), cnt.push_back(pw_n[k]),
+                                total_pts += (size_t)pw_n[k] + 1;
+                        q_off[k + 1] = (uint32_t)total_pts;
+                    }
+                    std::vector<float> pts(total_pts * 3);
+                    if ((rc = bezier_points(c, anc.data(), anc.size() / 3, first.data(), off.data(), cnt.data(), first.size(), total_pts, pts.data())) != HYAS_OK)
+                        return rc;
+                    pool.run(nsq, [&](size_t a, size_t b) {
+                        for (size_t k = a; k < b; ++k)
+                        {
+                            Query &q = Q[shot_q[k]];
+                            // piecewise path, then the analytic path once more (:181, :221)
+                            std::vector<float> pw(pts.begin() + 3 * (size_t)q_off[k], pts.begin() + 3 * (size_t)q_off[k + 1]);
+                            pw.insert(pw.end(), shot_buf.begin() + 3 * (size_t)h_off[k], shot_buf.begin() + 3 * ((size_t)h_off[k] + h_cnt[k]));
+                            pw.push_back(q.goal.x), pw.push_back(q.goal.y), pw.push_back(q.goal.t);
+                            q.path.swap(pw);
+                            D.finish(q, HYAS_STATUS_SHOT, q.shot_from, 2); // RemoveDuplicates of :184 / :224 and of :994
+                        }
+                    });
+                }
             }
         }
 

@@ -122,3 +122,23 @@ def test_reference_defaults_plan(oracle_built):
     p.res, p.ox, p.oy = 1.0, 0.0, 0.0
     s, g = p.free_poses(32, 75), p.free_poses(32, 76)
     _plan_compare(p, s, g)
+
+
+@pytest.mark.parametrize("every_point", [1, 0])
+def test_piecewise_bezier_interpolation(oracle_built, every_point):
+    """HybridAStar::ConvertToPiecewiseCubicBezierPath (src/hybrid_a_star.cpp:830-883): the traced part of a path that an
+    analytic shot closed is replaced by cubic Bezier curves between nodes at least one cell apart; with the adaptive step
+    size (steps of several cells) and with the fixed 0.2 step (no two anchors: the traced part drops out)."""
+    found = 0
+    for kw in (dict(adaptive_step_size=1), dict(adaptive_steering_angle_and_step_size=1, curve_type=2, min_turning_radius=2.0,
+                                                cd_min_turning_radius=2.0), dict()):
+        p = Pair("map_maze", position_resolution=1, max_iterations=400, piecewise_cubic_bezier_interpolation=1,
+                 analytical_expansion_every_point=every_point, short_cut=every_point, **kw)
+        s, g = p.free_poses(40, 77), p.free_poses(40, 78)
+        res = _plan_compare(p, s, g)
+        shot = res["status"] == hl.STATUS_SHOT
+        found += int(shot.sum())
+        for i in np.flatnonzero(shot)[:8]:
+            path = p.h.path(i)
+            assert np.allclose(path[-1], g[i]) and np.isfinite(path).all()
+    assert found >= 10

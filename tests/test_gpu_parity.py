@@ -430,7 +430,7 @@ def test_abi_error_behaviour():
     L = hl.load_library()
     # unsupported parameter sets are refused at creation
     for kw in (dict(adaptive_step_size=1, consider_steering_angle_range_for_obstacle_density=1),
-               dict(adaptive_steering_angle_and_step_size=1, obstacle_detection_range=0.0), dict(piecewise_cubic_bezier_interpolation=1),
+               dict(adaptive_steering_angle_and_step_size=1, obstacle_detection_range=0.0), dict(map_boundary_obstacle=1),
                dict(curve_type=3), dict(curve_type=-1),
                dict(vehicle_width=-1.0), dict(min_turning_radius=0.0), dict(number_of_successors=0), dict(headings=0)):
         p = hl.hot_path_params(**kw)

@@ -331,3 +331,37 @@ def test_bezier_table_and_shot_against_float64(oracle_built, libm):
     res, path, _ = o.plan((5, 5, 0), (25, 5, 0))
     assert res["status"] == 2  # the analytic shot connected
     assert len(path) > 10 and np.allclose(path[-1], (25, 5, 0)) and np.allclose(path[:, 1], 5, atol=1e-5)
+
+
+def test_piecewise_bezier_path_shape(oracle_built):
+    """ConvertToPiecewiseCubicBezierPath restated (parity unpinned: the reference holds no output for it).  With steps of
+    several cells the interpolated path of a search that an analytic shot closed starts near the start pose, ends at the
+    goal and is made of short hops (curve samples about a cell apart, then the analytic curve's samples), while the plain
+    path of the same search has hops of several cells."""
+    grid = orc.load_map("map_maze")
+    kw = dict(position_resolution=1, adaptive_step_size=1, analytical_expansion_every_point=0, min_turning_radius=2.0, cd_min_turning_radius=2.0,
+              max_iterations=2000)
+    o = orc.Oracle(orc.hot_path_params(piecewise_cubic_bezier_interpolation=1, **kw))
+    plain = orc.Oracle(orc.hot_path_params(**kw))
+    for x in (o, plain):
+        x.set_costmap(grid, build_table=True, nthreads=8)
+    rng = np.random.default_rng(17)
+    hits = 0
+    for _ in range(60):
+        s = (rng.uniform(2, 48), rng.uniform(2, 48), rng.uniform(0, 6.28))
+        g = (rng.uniform(2, 48), rng.uniform(2, 48), rng.uniform(0, 6.28))
+        if not o.collision(np.array([s, g], np.float32)).all():
+            continue
+        res, path, _ = o.plan(s, g)
+        res0, path0, _ = plain.plan(s, g)
+        assert res["status"] == res0["status"] and res["nodes_expanded"] == res0["nodes_expanded"]
+        hop0 = np.hypot(np.diff(path0[:, 0]), np.diff(path0[:, 1])) if len(path0) > 1 else np.zeros(1)
+        if res["status"] != 2 or hop0.max() < 2.0:
+            continue
+        hop = np.hypot(np.diff(path[:, 0]), np.diff(path[:, 1]))
+        if len(path) <= len(path0) - 0:  # fewer than two anchors: the traced part dropped out
+            continue
+        hits += 1
+        assert np.allclose(path[-1], g, atol=1e-5) and np.isfinite(path).all()
+        assert hop.max() < hop0.max()
+    assert hits >= 3
