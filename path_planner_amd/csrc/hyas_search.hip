@@ -909,7 +909,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             std::vector<size_t> bounds;
             size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
             std::atomic<uint32_t> claim{0}; // nodes of the launch being assembled that the workers have claimed
-            double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0;
+            double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0, t_sub = 0, t_turn = 0, t_idle = 0, t_done = 0;
             int64_t launches = 0;
             int rc = HYAS_OK;
         } G[HYAS_MAX_GROUPS];
@@ -1040,6 +1040,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             hipEvent_t *ev = c->round_ev[gi];
             const size_t s0 = g.s0, ns = g.ns;
             const double t0 = now();
+            g.t_sub = t0;
+            if (g.t_done > 0)
+                g.t_idle += t0 - g.t_done;
             size_t p_succ, p_len, p_ok, p_cnt;
             slice(g, p_succ, p_len, p_ok, p_cnt);
             const StepIn *d_in = k_in + s0 * KS;
@@ -1063,6 +1066,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             float ms = 0;
             if (hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
                 g.k_ms += ms;
+            g.t_done = now();
+            g.t_turn += (g.t_done - g.t_sub) - (double)ms * 1e-3;
             g.launches += 1;
             return HYAS_OK;
         };
@@ -1119,6 +1124,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             t_host = std::max(t_host, G[gi].t_host), t_launch = std::max(t_launch, G[gi].t_launch), t_wait = std::max(t_wait, G[gi].t_wait);
         }
 
+        if (trace_on)
+            for (int gi = 0; gi < ng; ++gi)
+                fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host %.3f s launch %.3f s wait %.3f s\n",
+                        gi, (long long)G[gi].launches, G[gi].k_ms * 1e3 / std::max<int64_t>(G[gi].launches, 1), G[gi].t_turn * 1e6 / std::max<int64_t>(G[gi].launches, 1),
+                        G[gi].t_idle * 1e6 / std::max<int64_t>(G[gi].launches, 1), G[gi].t_host, G[gi].t_launch, G[gi].t_wait);
         if (trace_on)
             fprintf(stderr,
                     "hyas rounds (%d groups, %d drivers x %d threads, %d nodes per query; slowest group): host push+pop %.3f s, launch %.3f s, "
