@@ -66,6 +66,19 @@ def _newest_profile(pattern):
 FOOTPRINTS = {"in_tree": (0.18, 0.22), "car": (2.0, 4.5)}
 
 
+def _footprint_l2(prof, avg_ms):
+    """What bounds the kernel: every random 8-byte gather from the occupancy bits moves a whole 128-byte line from L2
+    to a compute unit's L1 (the bits of a 4096 x 4096 grid are 2 MB: resident in L2, far too large for L1 or LDS)."""
+    if not prof:
+        return None
+    req = prof["counters_per_launch"].get("TCC_REQ_sum")
+    if not req:
+        return None
+    gbs = req * 128.0 / (avg_ms * 1e-3) / 1e9
+    return {"l2_requests_per_launch": req, "bytes_per_request": 128, "achieved_GBps": gbs, "peak_GBps": 34500.0, "frac": gbs / 34500.0,
+            "note": "requests x 128 B over the launch duration measured in this run; L2 peak = 16 channels x 128 B/clk x 8 XCDs x 2.1 GHz"}
+
+
 def footprint_checks(args, footprint="in_tree"):
     torch, dist, rank, local_rank, world = _dist_setup()
     from path_planner_amd import Hyas, default_params
@@ -132,8 +145,10 @@ def footprint_checks(args, footprint="in_tree"):
                    "free_fraction_rank0": free / n, "mean_cells_per_check": mean_len},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "frac_of_achievable_6300": achieved / 6300.0,
-                     "traffic": prof.get("hbm_bytes_per_launch") if prof else None, "kernel": "k_collision_footprint_window",
-                     "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch, "counters": prof},
+                     "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
+                     "kernel": (prof or {}).get("kernel", "k_collision_footprint_m8" if footprint == "in_tree" else "k_collision_footprint_window"),
+                     "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "l2": _footprint_l2(prof, avg_ms), "counters": prof},
         "cpu_baseline": cpu,
     }
 

@@ -51,6 +51,7 @@ struct hyas_ctx
     uint64_t *d_occ_tiles = nullptr;
     hyas::FpPack *d_fp_pack = nullptr;
     uint32_t *d_fp_win = nullptr;
+    uint64_t *d_occ_pad = nullptr, *d_fp_m8 = nullptr;
     float *d_table = nullptr;
     float *d_tab_xs = nullptr, *d_tab_ys = nullptr, *d_tab_ts = nullptr;
     double *d_seg = nullptr;

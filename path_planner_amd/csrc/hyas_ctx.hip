@@ -460,7 +460,7 @@ static void free_map(hyas_ctx *c)
 {
     void *ptrs[] = {c->d_charmap, c->d_quads, c->d_cell_off, c->d_cell_idx, c->d_fp, c->d_table, c->d_tab_xs, c->d_tab_ys, c->d_tab_ts, c->d_seg,
                     c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, c->d_occ_tiles, c->d_fp_pack, c->d_seg_db, c->d_fp_win,
-                    c->d_ad_off, c->d_ad_rng, c->d_ad_density};
+                    c->d_ad_off, c->d_ad_rng, c->d_ad_density, c->d_occ_pad, c->d_fp_m8};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -468,7 +468,7 @@ static void free_map(hyas_ctx *c)
     c->d_table = nullptr, c->d_tab_xs = c->d_tab_ys = c->d_tab_ts = nullptr, c->d_seg = nullptr;
     c->d_pose_off = c->d_seg_off = nullptr, c->d_pose_idx = c->d_seg_idx = nullptr;
     c->d_occ_tiles = nullptr, c->d_fp_pack = nullptr, c->d_seg_db = nullptr, c->d_fp_win = nullptr;
-    c->d_ad_off = nullptr, c->d_ad_rng = nullptr, c->d_ad_density = nullptr;
+    c->d_ad_off = nullptr, c->d_ad_rng = nullptr, c->d_ad_density = nullptr, c->d_occ_pad = nullptr, c->d_fp_m8 = nullptr;
     c->ad_off.clear(), c->ad_rng.clear(), c->ad_density.clear(), c->ad_min_distance.clear();
     c->tab_xs.clear(), c->tab_ys.clear(), c->tab_ts.clear();
     c->table_size = 0, c->twod_size = 0, c->seg_cap = 0;
@@ -540,6 +540,29 @@ static int upload_footprint_forms(hyas_ctx *c)
             if ((rc = upload(c, c->d_fp_win, win)) != HYAS_OK)
                 return rc;
             m.fp_win = c->d_fp_win, m.fp_bb = bb, m.fp_win_words = words;
+        }
+        // boxes of up to 7 cells: the same bitmaps with one byte per box row, and the tiles with an all-ones border
+        m.fp_m8 = nullptr, m.occ_pad = nullptr;
+        if (m.fp_win && bb <= 7 && n_entries * 8 <= 100 * 1024 && !std::getenv("HYAS_FP_ROWS"))
+        {
+            std::vector<uint64_t> m8(n_entries, 0);
+            for (size_t e = 0; e < n_entries; ++e)
+            {
+                const uint32_t *src = &win[e * words];
+                auto bit = [&](int b) { return (uint64_t)((src[b >> 5] >> (b & 31)) & 1u); };
+                for (int i = 0; i < bb; ++i)
+                    for (int j = 0; j < bb; ++j)
+                        m8[e] |= bit(i * bb + j) << (8 * i + j);
+                m8[e] |= bit(bb * bb) << 62 | bit(bb * bb + 1) << 63;
+            }
+            const uint32_t pitch = tx + 3;
+            std::vector<uint64_t> pad((size_t)pitch * (ty + 3), ~0ull);
+            for (uint32_t y = 0; y < ty; ++y)
+                for (uint32_t x = 0; x < tx; ++x)
+                    pad[(size_t)(y + 1) * pitch + x + 1] = tiles[(size_t)y * tx + x];
+            if ((rc = upload(c, c->d_fp_m8, m8)) != HYAS_OK || (rc = upload(c, c->d_occ_pad, pad)) != HYAS_OK)
+                return rc;
+            m.fp_m8 = c->d_fp_m8, m.occ_pad = c->d_occ_pad;
         }
     }
     const size_t entries = c->fp.size() / 129;

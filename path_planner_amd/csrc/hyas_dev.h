@@ -111,7 +111,13 @@ struct DevMap
     //             cell (j, i) of the box), fp_win_words 32-bit words per list; the two bits after the bitmap say
     //             whether the box sits fp_bb / 2 or fp_bb / 2 + 1 cells left of / below the pose's cell; null when
     //             the box is wider than 9 cells (a box of up to 9 cells spans at most 2 x 2 bit tiles)
+    //  fp_m8:     (boxes of up to 7 cells) every list as an 8 x 8 bitmap, byte i = row i of the box, bit j = cell (j, i);
+    //             bits 62 / 63: the box sits one cell further left / down (as in fp_win); occ_pad: the tiles with a
+    //             border of all-ones tiles, one to the left and above, two to the right and below:
+    //             tile (tx, ty) at (ty + 1) * (tiles_x + 3) + tx + 1 for -1 <= tx <= tiles_x + 1
     const uint64_t *occ_tiles;
+    const uint64_t *occ_pad;
+    const uint64_t *fp_m8;
     uint32_t tiles_x, tiles_y;
     const uint32_t *fp_win;
     int32_t fp_bb, fp_win_words;

@@ -36,6 +36,7 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
                    hyas_succ *succ, unsigned long long *stats, int stats_mode, hipStream_t s);
 void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                     uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s);
+hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode);
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
                   int stats_mode, hipStream_t s);

@@ -295,6 +295,107 @@ __global__ void __launch_bounds__(BB <= 5 ? 512 : 1024) k_collision_footprint_wi
     }
 }
 
+// Footprint-list mode for boxes of up to 7 cells, the lists as 8 x 8 bitmaps (DevMap::fp_m8): instead of cutting the
+// box out of the occupancy tiles, the bitmap is moved into tile coordinates.  The box's corner lies at (sx, sy) inside
+// tile (tx0, ty0): the columns that stay in the left tile are shifted up by sx inside every row byte, the others down
+// by 8 - sx into the right tile, and a shift by sy bytes splits both into the part over the upper and the lower tile.
+// A tile is fetched iff its part of the bitmap is not empty, and the pose is free iff no fetched tile has a bit in
+// common with its part.  Tiles off the grid come from the all-ones border of occ_pad (coordinates clamped to it).
+// Four poses per thread and iteration, one 4-byte verdict store; poses arrive through a per-wave strip of LDS.
+__global__ void __launch_bounds__(1024) k_collision_footprint_m8(DevMap m, int half_box, const float *__restrict__ xyt, size_t n, uint8_t *__restrict__ out)
+{
+    extern __shared__ uint32_t s_win[];
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    {
+        const uint32_t total = m.fp_entries * 2;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(m.fp_m8);
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
+            s_win[i] = src[i];
+    }
+    __syncthreads();
+    const HYAS_LDS u32x2 *s_m8 = (const HYAS_LDS u32x2 *)s_win;
+    const int pr = m.pr;
+    const size_t groups = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(xyt);
+    HYAS_LDS f32x4 *strip = (HYAS_LDS f32x4 *)(s_win + ((m.fp_entries * 2 + 3u) & ~3u)) + (threadIdx.x >> 6) * 192;
+    const int lane = threadIdx.x & 63;
+    const int pitch = (int)m.tiles_x + 3;
+    const int tx_max = (int)m.tiles_x, ty_max = (int)m.tiles_y;
+    for (size_t w0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) & ~(size_t)63; w0 < groups; w0 += stride)
+    {
+        const size_t g = w0 + lane;
+        f32x4 a = {0, 0, 0, 0}, b = a, c = a;
+        if (w0 + 64 <= groups) // uniform across the wave
+        {
+            f32x4 l[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                l[j] = __builtin_nontemporal_load(src + 3 * w0 + j * 64 + lane);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                strip[j * 64 + lane] = l[j];
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the strip is the wave's own: order, no barrier
+            a = strip[3 * lane], b = strip[3 * lane + 1], c = strip[3 * lane + 2];
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        else if (g < groups)
+            a = src[3 * g], b = src[3 * g + 1], c = src[3 * g + 2];
+        const float px[4] = {a.x, a.w, b.z, c.y}, py[4] = {a.y, b.x, b.w, c.z}, pt[4] = {a.z, b.y, c.x, c.w};
+        uint64_t part[4][4], tile[4][4];
+        bool in_table[4];
+        // pass 1: the bitmap's four parts, tile gathers requested
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const float x = px[k], y = py[k];
+            // |x|, |y| < 2^31 (false for NaN): there (long)x == (int)x, so the fraction needs no 64-bit conversion.
+            // Anything else is off the grid for the reference as well (its int conversion yields INT_MIN).
+            const bool sane = hy_fabsf(x) < 2147483648.f && hy_fabsf(y) < 2147483648.f && pt[k] == pt[k];
+            const int X = (int)x, Y = (int)y;
+            int iX = (int)((x - (float)X) * pr);
+            iX = iX > 0 ? iX : 0;
+            int iY = (int)((y - (float)Y) * pr);
+            iY = iY > 0 ? iY : 0;
+            const int iT = (int)(pt[k] / m.delta_heading);
+            in_table[k] = sane && !(iT < 0 || iT >= m.headings || iX >= pr || iY >= pr);
+            const uint32_t entry = in_table[k] ? (uint32_t)((iY * pr + iX) * m.headings + iT) : 0u;
+            const u32x2 raw = s_m8[entry];
+            const uint32_t mlo = in_table[k] ? raw.x : 0u, mhi = in_table[k] ? (raw.y & 0x00FFFFFFu) : 0u;
+            const int wx0 = X - (half_box + (int)((raw.y >> 30) & 1u)), wy0 = Y - (half_box + (int)(raw.y >> 31));
+            const uint32_t sx = (uint32_t)wx0 & 7u, sh = ((uint32_t)wy0 & 7u) * 8u;
+            const uint32_t keep = 0x01010101u * (0xFFu >> sx); // box columns that stay in the left tile, in every row byte
+            const uint64_t left = ((uint64_t)((mhi & keep) << sx) << 32) | ((mlo & keep) << sx);
+            const uint64_t right = ((uint64_t)((mhi & ~keep) >> (8u - sx)) << 32) | ((mlo & ~keep) >> (8u - sx));
+            part[k][0] = left << sh, part[k][1] = right << sh;
+            part[k][2] = (left >> 1) >> (63u - sh), part[k][3] = (right >> 1) >> (63u - sh); // sh == 0: nothing below
+            // tile (tx0, ty0) and its three neighbours, clamped onto the all-ones border
+            const int tx0 = min(max(wx0 >> 3, -1), tx_max), ty0 = min(max(wy0 >> 3, -1), ty_max);
+            const uint64_t *t0 = m.occ_pad + ((ty0 + 1) * pitch + tx0 + 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                tile[k][t] = part[k][t] ? t0[(t >> 1) * pitch + (t & 1)] : 0ull;
+        }
+        // pass 2
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const uint64_t hit = (tile[k][0] & part[k][0]) | (tile[k][1] & part[k][1]) | (tile[k][2] & part[k][2]) | (tile[k][3] & part[k][3]);
+            v |= (in_table[k] && hit == 0) ? 1u << (8 * k) : 0u;
+        }
+        if (g < groups)
+            __builtin_nontemporal_store(v, reinterpret_cast<uint32_t *>(out + 4 * g));
+    }
+    // the last n % 4 poses
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+    {
+        const size_t i = (n & ~(size_t)3) + threadIdx.x;
+        out[i] = footprint_free(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]) ? 1 : 0;
+    }
+}
+
 // --------------------------------------------------------------- map ingest
 // flags[c * n_quads + q] = 1 iff quad q is within `range` of the cell corner
 // (xs[c / nys], ys[c % nys]): the test of src/collisiondetection.cpp:335-343.
@@ -1676,7 +1777,18 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
     if (n == 0)
         return;
     static const bool force_packed_lists = std::getenv("HYAS_FP_PACKED_LISTS") != nullptr; // the per-cell kernel, for comparison
-    if (mode == HYAS_MODE_FOOTPRINT && m.fp_win && m.occ_tiles && (m.fp_bb == 5 || m.fp_bb == 7 || m.fp_bb == 9) && !force_packed_lists)
+    if (mode == HYAS_MODE_FOOTPRINT && m.fp_m8 && m.occ_pad && !force_packed_lists)
+    {
+        // one workgroup of sixteen waves per compute unit: bitmaps (8 bytes per list) and the waves' pose strips in LDS
+        const int threads = 1024;
+        const size_t lds = (((size_t)m.fp_entries * 2 + 3) & ~(size_t)3) * sizeof(uint32_t) + (size_t)(threads / 64) * 192 * 16;
+        const int blocks = (int)std::max<size_t>(1, std::min<size_t>(256, (n / 4 + threads - 1) / threads));
+        static size_t lds_m8 = 0;
+        if (lds_m8 < lds && hipFuncSetAttribute((const void *)k_collision_footprint_m8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            lds_m8 = lds;
+        hipLaunchKernelGGL(k_collision_footprint_m8, dim3(blocks), dim3(threads), lds, s, m, m.fp_bb / 2, xyt, n, out);
+    }
+    else if (mode == HYAS_MODE_FOOTPRINT && m.fp_win && m.occ_tiles && (m.fp_bb == 5 || m.fp_bb == 7 || m.fp_bb == 9) && !force_packed_lists)
     {
         // persistent grid: as many workgroups as fit on the chip, grid-stride over groups of four poses
         const int threads = m.fp_bb <= 5 ? 512 : 1024;
@@ -1862,6 +1974,40 @@ struct LaunchRound
         with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
     }
 };
+
+// Resolves the round kernel variant the next launches will use (the runtime loads a kernel's code object and looks the
+// function up the first time it is asked for it): called once on the thread that owns the context, so that the driver
+// threads, which make their first launches at the same moment, find that work done.
+template <int MODE, int CURVE>
+struct ResolveRound
+{
+    template <int ADAPT>
+    static void with(hipError_t *e)
+    {
+        hipFuncAttributes attr;
+        *e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_round<MODE, CURVE, ADAPT>));
+    }
+    static void go(const DevMap &m, hipError_t *e)
+    {
+        if constexpr (MODE == 0)
+        {
+            if (m.ad_mode == 1)
+                return with<1>(e);
+            if (m.ad_mode == 2)
+                return with<2>(e);
+        }
+        with<0>(e);
+    }
+};
+hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode)
+{
+    int mode = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;
+    if (m.ad_mode != 0)
+        mode = 0;
+    hipError_t e = hipSuccess;
+    dispatch_mode_curve<ResolveRound>(m, mode, &e);
+    return e;
+}
 
 void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                  uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s)

@@ -639,6 +639,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     c->expanded.assign(n, std::vector<int32_t>());
     if (n == 0)
         return HYAS_OK;
+    // the round kernel is looked up here, once, before several driver threads launch it at the same moment
+    HYAS_HIP(c, resolve_round_kernel(m, c->stats_on, c->stats_mode));
     if (!c->pools)
         c->pools = new SearchPools();
     Pool &pool = c->pools->main_pool(host_threads());
