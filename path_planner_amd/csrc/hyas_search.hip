@@ -925,7 +925,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::vector<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
         std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
         const bool P_analytic = c->P.analytical_expansion != 0;
-        std::atomic<uint64_t> spec_hits{0};
+        std::atomic<uint64_t> spec_hits{0}, miss_child{0}, miss_other{0};
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // where a group's results of the current round lie in the staging block (laid out for its current size)
         auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
@@ -976,7 +976,18 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                                 if (q.spec[i] == q.cur)
                                     j = i;
                             if (j < 0)
+                            {
+                                if (trace_on)
+                                {
+                                    // why the round ends: the popped node is a successor pushed during this round, or
+                                    // an older open-list entry beyond the ones sent along
+                                    bool child = false;
+                                    for (int i = 0; i < q.nspec; ++i)
+                                        child = child || q.arena[q.cur].pred == q.spec[i];
+                                    (child ? miss_child : miss_other).fetch_add(1, std::memory_order_relaxed);
+                                }
                                 break; // no: it goes to the GPU
+                            }
                             at = j;
                             deepest = std::max(deepest, j);
                             ++hits;
@@ -1126,6 +1137,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             t_host = std::max(t_host, G[gi].t_host), t_launch = std::max(t_launch, G[gi].t_launch), t_wait = std::max(t_wait, G[gi].t_wait);
         }
 
+        if (trace_on)
+            fprintf(stderr, "hyas rounds ended by: a successor of a node of the same round %llu, an older open-list entry %llu; answered ahead %llu\n",
+                    (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)spec_hits.load());
         if (trace_on)
             for (int gi = 0; gi < ng; ++gi)
                 fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host %.3f s launch %.3f s wait %.3f s\n",
