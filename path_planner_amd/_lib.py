@@ -168,6 +168,25 @@ def hot_path_params(**kw):
     return p
 
 
+# The parameter file the reference ships (param/parameters.yaml:1-140), restricted to the keys this path reads.
+# cd_min_turning_radius follows min_turning_radius: both are read from the same yaml key
+# (src/parameter_manager.cpp:149-150, :233-234).
+SHIPPED_YAML = dict(
+    reverse=0, short_cut=1, piecewise_cubic_bezier_interpolation=1, number_of_successors=5, curve_type=2,
+    adaptive_steering_angle_and_step_size=1, adaptive_step_size=0, constant_density=0.6, obstacle_detection_range=1.0,
+    add_one_more_successor=0, add_one_more_successor_only_in_free_angle_range=1, map_boundary_obstacle=0,
+    steering_angle_towards_free_angle_range_for_obstacle_angle_range=1, fixed_number_of_steering_angle_in_free_angle_range=1,
+    analytical_expansion=1, analytical_expansion_every_point=0, consider_steering_angle_range_for_obstacle_density=0,
+    position_resolution=1, vehicle_width=0.25, vehicle_length=0.5, max_steering_angle=30.0, tie_breaker=0.01, goal_range=1.0,
+    penalty_turning=1.5, penalty_reverse=1.2, penalty_change_of_direction=1.0, steering_angle=3.0, curve_step_size=0.3,
+    headings=72, max_iterations=100000, min_turning_radius=0.35, cd_min_turning_radius=0.35)
+
+
+def shipped_yaml_params(**kw):
+    """hyas_default_params overridden by the reference's shipped parameter file, then by kw."""
+    return default_params(**{**SHIPPED_YAML, **kw})
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -142,3 +142,32 @@ def test_piecewise_bezier_interpolation(oracle_built, every_point):
             path = p.h.path(i)
             assert np.allclose(path[-1], g[i]) and np.isfinite(path).all()
     assert found >= 10
+
+
+@pytest.mark.parametrize("name,iters,detection_range", [("map_maze", 1500, 1.0), ("map_parking", 1500, 1.0), ("map_large", 600, 1.0),
+                                                        ("map_maze", 1500, 6.0), ("map_parking", 1500, 6.0), ("map_maze", 1500, 3.0)])
+def test_shipped_parameter_file_plan(oracle_built, name, iters, detection_range):
+    """The configuration the reference ships (param/parameters.yaml): cubic Bezier curves, adaptive steering angle and
+    step size, 0.25 x 0.5 m vehicle with a 0.35 m turning radius, shots at the paper's schedule, short cut and piecewise
+    Bezier interpolation of the result. Iterations are capped so that the scalar oracle finishes in seconds. On these
+    1 m maps the shipped obstacle_detection_range of 1 m leaves most nodes with one straight successor (a sweep that
+    meets no obstacle is stored with the cell's minimum distance, src/collisiondetection.cpp:480-487, and is then not
+    recognised as free, :764): the searches end with an empty open list after a few nodes, here as there. The same
+    file with the struct's range of 6 m, and with 3 m, searches properly."""
+    over = {"max_iterations": iters, "obstacle_detection_range": detection_range}
+    po = orc.default_params(**{**hl.SHIPPED_YAML, **over})
+    ph = hl.shipped_yaml_params(**over)
+    for f, _ in hl.Params._fields_:
+        assert getattr(po, f) == getattr(ph, f), f
+    p = Pair.__new__(Pair)
+    p.map = orc.load_map(name)
+    p.o = orc.Oracle(po)
+    p.o.set_costmap(p.map, build_table=True, nthreads=16)
+    p.h = hl.Hyas(ph)
+    p.h.set_costmap(p.map, build_table=True)
+    p.H, p.W = p.map.shape
+    p.res, p.ox, p.oy = 1.0, 0.0, 0.0
+    s, g = p.free_poses(32, 81), p.free_poses(32, 82)
+    res = _plan_compare(p, s, g)
+    if detection_range > 1.0 and name == "map_maze":
+        assert (res["status"] == hl.STATUS_SHOT).sum() >= 4
