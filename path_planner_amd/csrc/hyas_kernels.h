@@ -13,9 +13,10 @@ struct StepIn
     float x, y, t, g;
     int32_t prim;
     uint32_t query; // which goal / 2D cost map
-    uint32_t shoot; // 1: evaluate the analytic shot for this node
+    uint32_t shoot; // bit 0: evaluate the analytic shot for this node; STEP_DEAD: no node in this slot
     uint32_t pad;
 };
+#define STEP_DEAD 2u
 
 void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
 void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
@@ -39,7 +40,10 @@ void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal 
 hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode);
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                  int stats_mode, hipStream_t s);
+                  int stats_mode, hipStream_t s, StepIn *child = nullptr, bool child_shoot = false);
+// child (optional, n records in device memory): the launch also writes, for every node, the input record of its
+// lowest-f successor (shoot = child_shoot; STEP_DEAD when the node has none), ready to be the `in` of a further launch
+// on the same stream, and marks that successor's record with pad = 1.
 // paths: concatenated poses {x, y, t}; offs: n_paths + 1 pose offsets; out_idx: offs[n_paths] + n_paths entries; out_n: n_paths
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s);
 void launch_shortcut(const DevMap &m, const float *paths, const uint32_t *offs, uint32_t n_paths, uint32_t *out_idx, uint32_t *out_n, hipStream_t s);

@@ -849,7 +849,8 @@ struct ExpandShape
 template <int MODE, int ADAPT>
 __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__restrict__ in, uint32_t n, const hyas_goal *__restrict__ goals,
                                             const float *__restrict__ twod, uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
-                                            unsigned long long *stats, Quad *s_quads, uint32_t block)
+                                            unsigned long long *stats, Quad *s_quads, uint32_t block, StepIn *__restrict__ child = nullptr,
+                                            uint32_t child_shoot = 0)
 {
     constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES;
     const int tid = threadIdx.x;
@@ -861,8 +862,9 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     // (a wave that mixed the two would run them one after the other)
     const int lane = tid & 63, sl = tid & (LANES - 1), local = (tid & (EXPAND_THREADS / 2 - 1)) / LANES;
     const uint32_t slot = block * NODES + local;
-    const bool live = slot < n;
-    const StepIn node = in[live ? slot : 0];
+    const bool in_launch = slot < n;
+    const StepIn node = in[in_launch ? slot : 0];
+    const bool live = in_launch && (node.shoot & STEP_DEAD) == 0;
     const hyas_goal goal = goals[node.query];
     const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
     const bool pose_lane = tid < EXPAND_THREADS / 2, seg_lane = !pose_lane;
@@ -932,12 +934,36 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     constexpr unsigned long long GROUP = (1ull << LANES) - 1ull;
     const unsigned mask = (unsigned)((__ballot(ok) >> grp) & GROUP);
     const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & GROUP);
+    if (child)
+    {
+        // The successor with the lowest f = g + h (the earliest of equals: the one the open list would pop first)
+        // becomes node `slot` of the next, deeper launch; its record carries pad = 1 so that the host knows which
+        // one was taken without redoing the comparison.
+        float bf = ok ? s.g + s.h : INFINITY;
+        if (!(bf == bf))
+            bf = INFINITY;
+        int bi = ok ? sl : 255;
+        for (int off = LANES / 2; off > 0; off >>= 1)
+        {
+            const float of = __shfl_xor(bf, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (of < bf || (of == bf && oi < bi))
+                bf = of, bi = oi;
+        }
+        if (ok && bi == sl)
+        {
+            s.pad = 1;
+            child[slot] = StepIn{s.x, s.y, s.t, s.g, prim, node.query, child_shoot, node.pad};
+        }
+        if (in_launch && seg_lane && sl == 0 && bi == 255) // nothing to expand one level down
+            child[slot] = StepIn{node.x, node.y, node.t, node.g, node.prim, node.query, STEP_DEAD, node.pad};
+    }
     if (ok)
     {
         int pos = __popc(mask & ((1u << sl) - 1u));
         succ[(size_t)slot * m.n_slots + pos] = s;
     }
-    const bool writer = live && seg_lane && sl == 0;
+    const bool writer = in_launch && seg_lane && sl == 0;
     if (writer) // low nibble: emitted successors, high nibble: candidates that got a verdict
         count[slot] = overflow ? (uint8_t)0xFF : (uint8_t)(__popc(mask) | (__popc(emask) << 4));
     if (MODE == 1)
@@ -986,7 +1012,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     constexpr bool RS = CURVE == HYAS_CURVE_RS, BZ = CURVE == HYAS_CURVE_BEZIER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const StepIn node = in[slot];
-    if (node.shoot == 0) // uniform across the workgroup
+    if ((node.shoot & 1u) == 0) // uniform across the workgroup
     {
         if (tid == 0)
             shot_ok[slot] = 0, shot_len[slot] = 0;
@@ -1357,13 +1383,13 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
                                                                         const double *__restrict__ seg_tab, uint32_t seg_cap,
                                                                         uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
                                                                         uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
-                                                                        unsigned long long *stats)
+                                                                        unsigned long long *stats, StepIn *__restrict__ child, uint32_t child_shoot)
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
     if (blockIdx.x < n) // uniform across the workgroup
         shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
     else
-        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n);
+        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n, child, child_shoot);
 }
 
 // The accepted curves of n queries, one workgroup each: samples {x, y, t} of
@@ -1954,24 +1980,26 @@ struct LaunchRound
 {
     template <int ADAPT>
     static void with(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
-                     uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, hipStream_t s)
+                     uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, StepIn *child,
+                     uint32_t child_shoot, hipStream_t s)
     {
         constexpr uint32_t nodes = ExpandShape<ADAPT>::NODES;
         const dim3 grid(n + (n + nodes - 1) / nodes);
         hipLaunchKernelGGL((k_round<MODE, CURVE, ADAPT>), grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
-                           count, succ, stats);
+                           count, succ, stats, child, child_shoot);
     }
     static void go(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
-                   uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, hipStream_t s)
+                   uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, StepIn *child, uint32_t child_shoot,
+                   hipStream_t s)
     {
         if constexpr (MODE == 0) // the adaptive variants exist without counters only
         {
             if (m.ad_mode == 1)
-                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, s);
             if (m.ad_mode == 2)
-                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, s);
         }
-        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, s);
     }
 };
 
@@ -2020,14 +2048,15 @@ void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal 
 
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                  int stats_mode, hipStream_t s)
+                  int stats_mode, hipStream_t s, StepIn *child, bool child_shoot)
 {
     if (!n)
         return;
     int mode = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;
     if (m.ad_mode != 0)
         mode = 0;
-    dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, s);
+    dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child,
+                                     child_shoot ? 1u : 0u, s);
 }
 
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s)

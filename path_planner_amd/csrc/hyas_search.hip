@@ -25,7 +25,8 @@ namespace hyas
 namespace
 {
 
-#define HYAS_MAX_SPEC 8 // most nodes of one query in one round
+#define HYAS_MAX_SPEC 8  // most open-list nodes of one query in one round
+#define HYAS_MAX_DEPTH 4 // most launches per round: each expands the lowest-f successors of the one before
 
 struct SNode
 {
@@ -391,10 +392,13 @@ struct Driver
         return false;
     }
 
-    // Takes the kernel's answer for the node popped by advance() (:243-305).
-    void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ)
+    // Takes the kernel's answer for the node popped by advance() (:243-305).  best_child (optional): the arena index
+    // of the successor the kernel expanded one level down, -1 when that one was not pushed.
+    void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ, int32_t *best_child = nullptr)
     {
         const int32_t pid = q.cur;
+        if (best_child)
+            *best_child = -1;
         if (q.shoot && shot_ok)
         {
             q.shot_from = pid;
@@ -423,6 +427,12 @@ struct Driver
                     __builtin_prefetch(&q.dup_head[bucket_hash(bx, by + dy, dmask)]);
             }
         }
+        // the successor the kernel has sent on to the next, deeper launch of this round (marked pad = 1)
+        int kmin = -1;
+        if (best_child)
+            for (int k = 0; k < count; ++k)
+                if (succ[k].pad == 1)
+                    kmin = k;
         for (int k = 0; k < count; ++k)
         {
             const hyas_succ &s = succ[k];
@@ -444,6 +454,8 @@ struct Driver
                 }
                 cell.g = n.g, cell.open = 1, cell.closed = 0;
                 push(q, n, iSucc);
+                if (k == kmin)
+                    *best_child = (int32_t)q.arena.size() - 1;
             }
         }
     }
@@ -677,10 +689,19 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     int spec_cfg = 6;
     if (const char *e = std::getenv("HYAS_SPEC"))
         spec_cfg = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
+    // Launches per round.  The second launch expands, for every node of the first, its lowest-f successor (which the
+    // first launch left in device memory), the third does the same for the second: a search that keeps following
+    // its newest node is answered for several pops from one round trip.  The host consumes strictly in pop order and
+    // takes a deeper answer only when the node it pops is exactly the one that was expanded.
+    int depth_cfg = 1;
+    if (const char *e = std::getenv("HYAS_DEPTH"))
+        depth_cfg = std::min(HYAS_MAX_DEPTH, std::max(1, std::atoi(e)));
+    const size_t DEPTH = (size_t)depth_cfg;
     int drivers_cfg = 0;
     if (const char *e = std::getenv("HYAS_DRIVERS"))
         drivers_cfg = std::max(1, std::atoi(e));
     const bool trace_on = std::getenv("HYAS_TRACE") != nullptr;
+    const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : 1;
     std::vector<float> shot_buf;
     // a failed HIP call may leave kernels of other groups in flight that write into the staging block: wait for them
     auto drain = [&](int rc) {
@@ -706,7 +727,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // groups of a chunk hold ceil(cn / groups) queries each: at most cn + groups slots in all
     const size_t slots_max = cn_max + HYAS_MAX_GROUPS;
     const size_t o_in = take(slots_max * KS * sizeof(StepIn));
-    const size_t o_succ = take(res_stride(slots_max * KS) + HYAS_MAX_GROUPS * 512);
+    const size_t o_succ = take(DEPTH * (res_stride(slots_max * KS) + HYAS_MAX_GROUPS * 512));
+    const size_t child_stride = (slots_max * KS * sizeof(StepIn) + 255) & ~(size_t)255; // device side only
+    const size_t o_child = take((DEPTH - 1) * child_stride + 256);
     // set-up staging, per buffer set: goals, poses {start, goal}, relative poses for the table lookup, their results
     struct PrepOff
     {
@@ -912,7 +935,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
             std::atomic<uint32_t> claim{0}; // nodes of the launch being assembled that the workers have claimed
             double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0, t_sub = 0, t_turn = 0, t_idle = 0, t_done = 0;
-            int64_t launches = 0;
+            int64_t launches = 0, rounds = 0, timed_launches = 0;
+            bool timed = false; // the round in flight carries the two timing events
             int rc = HYAS_OK;
         } G[HYAS_MAX_GROUPS];
         for (int gi = 0; gi < ng; ++gi)
@@ -925,11 +949,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::vector<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
         std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
         const bool P_analytic = c->P.analytical_expansion != 0;
-        std::atomic<uint64_t> spec_hits{0}, miss_child{0}, miss_other{0};
+        std::atomic<uint64_t> spec_hits{0}, deep_hits{0}, miss_child{0}, miss_other{0};
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // where a group's results of the current round lie in the staging block (laid out for its current size)
-        auto slice = [&](const Group &g, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
-            size_t o = o_succ + (&g - G) * res_stride(gcap * KS);
+        auto slice = [&](const Group &g, size_t lvl, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
+            size_t o = o_succ + ((&g - G) * DEPTH + lvl) * res_stride(gcap * KS);
             p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
             p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
             p_ok = o, o += (g.ns + 15) & ~(size_t)15;
@@ -939,11 +963,18 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         // the next node of every query; false when all queries of the group have finished
         auto host_round = [&](Group &g, Pool &gp, bool have_results) -> bool {
             const double t0 = now();
-            size_t p_succ, p_len, p_ok, p_cnt;
-            slice(g, p_succ, p_len, p_ok, p_cnt);
-            const hyas_succ *r_succ = (const hyas_succ *)(hs + p_succ);
-            const float *r_len = (const float *)(hs + p_len);
-            const uint8_t *r_ok = (const uint8_t *)(hs + p_ok), *r_cnt = (const uint8_t *)(hs + p_cnt);
+            struct Level
+            {
+                const hyas_succ *succ;
+                const float *len;
+                const uint8_t *ok, *cnt;
+            } L[HYAS_MAX_DEPTH];
+            for (size_t l = 0; l < DEPTH; ++l)
+            {
+                size_t p_succ, p_len, p_ok, p_cnt;
+                slice(g, l, p_succ, p_len, p_ok, p_cnt);
+                L[l] = Level{(const hyas_succ *)(hs + p_succ), (const float *)(hs + p_len), (const uint8_t *)(hs + p_ok), (const uint8_t *)(hs + p_cnt)};
+            }
             // equal shares of the group's live queries, in index order: a query stays with the same worker from
             // round to round (its heap, cell map and duplicate hash stay in that core's cache) and only moves to a
             // neighbour when queries in front of it finish
@@ -953,7 +984,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             g.claim.store(0, std::memory_order_relaxed);
             gp.run_parts([&](int w) {
-                uint64_t hits = 0;
+                uint64_t hits = 0, deep = 0;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
@@ -961,19 +992,30 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     bool want;
                     if (have_results)
                     {
-                        int at = 0; // which of the query's nodes of the last launch is being consumed
+                        // the nodes this round holds answers for: the open-list entries sent along (first launch) and,
+                        // as they come into being, the successors that the deeper launches expanded
+                        int32_t ans_id[HYAS_MAX_SPEC * HYAS_MAX_DEPTH];
+                        uint8_t ans_lvl[HYAS_MAX_SPEC * HYAS_MAX_DEPTH], ans_at[HYAS_MAX_SPEC * HYAS_MAX_DEPTH];
+                        int n_ans = 0;
+                        for (int i = 1; i < q.nspec; ++i)
+                            ans_id[n_ans] = q.spec[i], ans_lvl[n_ans] = 0, ans_at[n_ans] = (uint8_t)i, ++n_ans;
+                        size_t lvl = 0;
+                        int at = 0; // which of the query's nodes of launch `lvl` is being consumed
                         int deepest = 0;
                         for (;;)
                         {
                             const size_t sl = slot0[qi] + at;
-                            D.consume(q, r_ok[sl], r_len[sl], r_cnt[sl], r_succ + sl * K);
+                            int32_t best_child = -1;
+                            D.consume(q, L[lvl].ok[sl], L[lvl].len[sl], L[lvl].cnt[sl], L[lvl].succ + sl * K, lvl + 1 < DEPTH ? &best_child : nullptr);
+                            if (best_child >= 0)
+                                ans_id[n_ans] = best_child, ans_lvl[n_ans] = (uint8_t)(lvl + 1), ans_at[n_ans] = (uint8_t)at, ++n_ans;
                             want = !q.done && D.advance(q);
                             if (!want)
                                 break;
-                            // the node popped now: was it expanded ahead of time?
+                            // the node popped now: does the round hold its answer?
                             int j = -1;
-                            for (int i = 1; i < q.nspec; ++i)
-                                if (q.spec[i] == q.cur)
+                            for (int i = 0; i < n_ans; ++i)
+                                if (ans_id[i] == q.cur)
                                     j = i;
                             if (j < 0)
                             {
@@ -988,9 +1030,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                                 }
                                 break; // no: it goes to the GPU
                             }
-                            at = j;
-                            deepest = std::max(deepest, j);
-                            ++hits;
+                            lvl = ans_lvl[j], at = ans_at[j];
+                            if (lvl == 0)
+                                deepest = std::max(deepest, at), ++hits;
+                            else
+                                ++deep;
                         }
                         // width of the next round: two beyond the deepest entry that was used, one less when none was
                         if (spec_adapt)
@@ -1016,6 +1060,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
                 if (hits)
                     spec_hits.fetch_add(hits, std::memory_order_relaxed);
+                if (deep)
+                    deep_hits.fetch_add(deep, std::memory_order_relaxed);
                 // This worker's nodes go into a range of the launch it claims in one step, copied by the thread
                 // that has just written them (one thread gathering everybody's nodes would fetch each line from
                 // another core's cache).  The order of the nodes within a launch is immaterial: results are found
@@ -1056,16 +1102,24 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             g.t_sub = t0;
             if (g.t_done > 0)
                 g.t_idle += t0 - g.t_done;
-            size_t p_succ, p_len, p_ok, p_cnt;
-            slice(g, p_succ, p_len, p_ok, p_cnt);
-            const StepIn *d_in = k_in + s0 * KS;
             if (c->d_nodes)
                 __builtin_ia32_sfence(); // the stores into device memory leave the write-combining buffers before the doorbell
-            (void)hipEventRecord(ev[0], st);
-            launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
-                         (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
-                         c->stats_mode, st);
-            (void)hipEventRecord(ev[1], st);
+            g.timed = ev_every > 0 && g.rounds % ev_every == 0;
+            g.rounds += 1;
+            if (g.timed)
+                (void)hipEventRecord(ev[0], st);
+            for (size_t l = 0; l < DEPTH; ++l)
+            {
+                size_t p_succ, p_len, p_ok, p_cnt;
+                slice(g, l, p_succ, p_len, p_ok, p_cnt);
+                const StepIn *d_in = l == 0 ? k_in + s0 * KS : (const StepIn *)(ds + o_child + (l - 1) * child_stride) + s0 * KS;
+                StepIn *d_child = l + 1 < DEPTH ? (StepIn *)(ds + o_child + l * child_stride) + s0 * KS : nullptr;
+                launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
+                             (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
+                             c->stats_mode, st, d_child, P_analytic);
+            }
+            if (g.timed)
+                (void)hipEventRecord(ev[1], st);
             hipError_t e = hipGetLastError();
             g.t_launch += now() - t0;
             return e == hipSuccess ? HYAS_OK : HYAS_ENODEV;
@@ -1077,11 +1131,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             if (e != hipSuccess)
                 return HYAS_ENODEV;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
-                g.k_ms += ms;
             g.t_done = now();
-            g.t_turn += (g.t_done - g.t_sub) - (double)ms * 1e-3;
-            g.launches += 1;
+            if (g.timed && hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
+            {
+                g.k_ms += ms, g.timed_launches += (int64_t)DEPTH;
+                g.t_turn += (g.t_done - g.t_sub) - (double)ms * 1e-3;
+            }
+            g.launches += (int64_t)DEPTH;
             return HYAS_OK;
         };
         // One driver thread (with its helpers) takes every n_drivers-th group and keeps all of them in flight:
@@ -1133,17 +1189,21 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         {
             if (G[gi].rc != HYAS_OK)
                 return drain(c->fail(G[gi].rc, "a HIP call failed in a search round"));
-            c->k_ms[0] += G[gi].k_ms, c->k_launches[0] += G[gi].launches;
+            // kernel time of all launches, from the ones that carried timing events
+            if (G[gi].timed_launches > 0)
+                c->k_ms[0] += G[gi].k_ms * (double)G[gi].launches / (double)G[gi].timed_launches, c->k_launches[0] += G[gi].launches;
             t_host = std::max(t_host, G[gi].t_host), t_launch = std::max(t_launch, G[gi].t_launch), t_wait = std::max(t_wait, G[gi].t_wait);
         }
 
         if (trace_on)
-            fprintf(stderr, "hyas rounds ended by: a successor of a node of the same round %llu, an older open-list entry %llu; answered ahead %llu\n",
-                    (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)spec_hits.load());
+            fprintf(stderr, "hyas rounds ended by: a successor of a node of the same round %llu, an older open-list entry %llu; answered ahead: "
+                            "open-list entries %llu, successors expanded by the deeper launches %llu (%d launches per round)\n",
+                    (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)spec_hits.load(),
+                    (unsigned long long)deep_hits.load(), depth_cfg);
         if (trace_on)
             for (int gi = 0; gi < ng; ++gi)
                 fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host %.3f s launch %.3f s wait %.3f s\n",
-                        gi, (long long)G[gi].launches, G[gi].k_ms * 1e3 / std::max<int64_t>(G[gi].launches, 1), G[gi].t_turn * 1e6 / std::max<int64_t>(G[gi].launches, 1),
+                        gi, (long long)G[gi].launches, G[gi].k_ms * 1e3 / std::max<int64_t>(G[gi].timed_launches, 1), G[gi].t_turn * 1e6 / std::max<int64_t>(G[gi].timed_launches / (int64_t)DEPTH, 1),
                         G[gi].t_idle * 1e6 / std::max<int64_t>(G[gi].launches, 1), G[gi].t_host, G[gi].t_launch, G[gi].t_wait);
         if (trace_on)
             fprintf(stderr,
