@@ -130,6 +130,14 @@ struct Query
     std::vector<float> path;
 };
 
+// HYAS_TRACE: where the host time of taking successors goes, per thread, flushed by the worker loop
+struct ConsumeProbe
+{
+    uint64_t dup = 0, cell = 0, push = 0, chain = 0, heads = 0, succ = 0, pushed = 0;
+};
+static thread_local ConsumeProbe t_probe;
+static bool g_probe_on = false;
+
 struct Driver
 {
     hyas_ctx *c;
@@ -183,18 +191,35 @@ struct Driver
             q.arena[n.dup_next].dup_prev = n.dup_prev;
         n.dup_next = -1, n.dup_prev = -1;
     }
+    // Which neighbouring buckets can hold an entry within 0.05 (half a bucket) of v: the lower one only from the
+    // bucket's lower half, the upper one only from its upper half.  The comparison below is made on the float
+    // difference, which is within a rounding step of the true one: the margin of a thousandth of a bucket is orders
+    // of magnitude wider.
+    static void bucket_reach(float v, int32_t &b, int &lo, int &hi)
+    {
+        const double u = (double)v * 10.0, fl = std::floor(u), f = u - fl;
+        b = (int32_t)fl;
+        lo = f < 0.501 ? -1 : 0;
+        hi = f > 0.499 ? 1 : 0;
+    }
     bool dup_exists(const Query &q, float x, float y, float t) const
     {
-        const int32_t bx = bucket_coord(x), by = bucket_coord(y);
+        int32_t bx, by;
+        int xlo, xhi, ylo, yhi;
+        bucket_reach(x, bx, xlo, xhi), bucket_reach(y, by, ylo, yhi);
         const size_t mask = q.dup_head.size() - 1;
         // two neighbours may share a bucket; scanning it twice does not change the answer
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = ylo; dy <= yhi; ++dy)
+            for (int dx = xlo; dx <= xhi; ++dx)
             {
                 const size_t b = bucket_hash(bx + dx, by + dy, mask);
+                if (g_probe_on && q.dup_head[b] >= 0)
+                    t_probe.heads += 1;
                 for (int32_t id = q.dup_head[b]; id >= 0; id = q.arena[id].dup_next)
                 {
                     const SNode &e = q.arena[id];
+                    if (g_probe_on)
+                        t_probe.chain += 1;
                     if ((double)hy_fabsf(e.x - x) < 0.05 && (double)hy_fabsf(e.y - y) < 0.05 && hy_fabsf(e.t - t) < rad3)
                         return true;
                 }
@@ -417,14 +442,11 @@ struct Driver
         count &= 15;
         // the lookups below miss the cache independently of each other: request all their lines first
         {
-            const size_t cmask = q.cells.slots.size() - 1, dmask = q.dup_head.size() - 1;
+            const size_t cmask = q.cells.slots.size() - 1;
             for (int k = 0; k < count; ++k)
             {
                 const hyas_succ &s = succ[k];
                 __builtin_prefetch(&q.cells.slots[CellMap::hash(s.idx) & cmask]);
-                const int32_t bx = bucket_coord(s.x), by = bucket_coord(s.y);
-                for (int dy = -1; dy <= 1; ++dy)
-                    __builtin_prefetch(&q.dup_head[bucket_hash(bx, by + dy, dmask)]);
             }
         }
         // the successor the kernel has sent on to the next, deeper launch of this round (marked pad = 1)
@@ -433,30 +455,38 @@ struct Driver
             for (int k = 0; k < count; ++k)
                 if (succ[k].pad == 1)
                     kmin = k;
+        // The reference tests, in this order: duplicate of an open-list entry, cell closed, not better than the cell's
+        // g, same cell as the predecessor and beyond the tie breaker (:255-283).  Each of them only drops the
+        // successor, so their order does not matter: the cell tests come first here because they are cheaper and
+        // drop most successors, and the duplicate check (a walk over neighbouring open-list entries) runs for the rest.
         for (int k = 0; k < count; ++k)
         {
             const hyas_succ &s = succ[k];
-            if (dup_exists(q, s.x, s.y, s.t))
-                continue;
+            const uint64_t p0 = g_probe_on ? __builtin_ia32_rdtsc() : 0;
             const int32_t iSucc = s.idx;
-            CellMap::Slot &cell = q.cells.get(iSucc);
-            if (cell.closed)
-                continue;
+            CellMap::Slot *seen = q.cells.find(iSucc);
+            t_probe.succ += 1;
+            const uint64_t p1 = g_probe_on ? __builtin_ia32_rdtsc() : 0;
+            t_probe.cell += p1 - p0;
             const float newG = s.g;
-            if (!cell.open || newG < cell.g)
-            {
-                SNode n{s.x, s.y, s.t, s.g, s.h, (int32_t)s.prim, pid, -1, -1};
-                if (q.cur_idx == iSucc)
-                {
-                    if (n.g + n.h > pred.g + pred.h + P.tie_breaker)
-                        continue;
-                    n.pred = pred.pred;
-                }
-                cell.g = n.g, cell.open = 1, cell.closed = 0;
-                push(q, n, iSucc);
-                if (k == kmin)
-                    *best_child = (int32_t)q.arena.size() - 1;
-            }
+            if (seen && (seen->closed || (seen->open && !(newG < seen->g))))
+                continue;
+            const bool same_cell = q.cur_idx == iSucc;
+            if (same_cell && s.g + s.h > pred.g + pred.h + P.tie_breaker)
+                continue;
+            const bool dup = dup_exists(q, s.x, s.y, s.t);
+            const uint64_t p2 = g_probe_on ? __builtin_ia32_rdtsc() : 0;
+            t_probe.dup += p2 - p1;
+            if (dup)
+                continue;
+            SNode n{s.x, s.y, s.t, s.g, s.h, (int32_t)s.prim, same_cell ? pred.pred : pid, -1, -1};
+            CellMap::Slot &cell = seen ? *seen : q.cells.get(iSucc);
+            cell.g = n.g, cell.open = 1, cell.closed = 0;
+            push(q, n, iSucc);
+            if (g_probe_on)
+                t_probe.push += __builtin_ia32_rdtsc() - p2, t_probe.pushed += 1;
+            if (k == kmin)
+                *best_child = (int32_t)q.arena.size() - 1;
         }
     }
 };
@@ -950,6 +980,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
         const bool P_analytic = c->P.analytical_expansion != 0;
         std::atomic<uint64_t> spec_hits{0}, deep_hits{0}, miss_child{0}, miss_other{0};
+        std::atomic<uint64_t> cyc_consume{0}, cyc_advance{0}, cyc_next{0}, cyc_copy{0}; // host time by part, HYAS_TRACE only
+        std::atomic<uint64_t> pr_dup{0}, pr_cell{0}, pr_push{0}, pr_chain{0}, pr_heads{0}, pr_succ{0}, pr_pushed{0};
+        g_probe_on = trace_on;
+        auto tick = [trace_on]() -> uint64_t { return trace_on ? __builtin_ia32_rdtsc() : 0; };
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // where a group's results of the current round lie in the staging block (laid out for its current size)
         auto slice = [&](const Group &g, size_t lvl, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
@@ -984,7 +1018,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             g.claim.store(0, std::memory_order_relaxed);
             gp.run_parts([&](int w) {
-                uint64_t hits = 0, deep = 0;
+                uint64_t hits = 0, deep = 0, c_consume = 0, c_advance = 0, c_next = 0;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
@@ -1006,10 +1040,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                         {
                             const size_t sl = slot0[qi] + at;
                             int32_t best_child = -1;
+                            const uint64_t c0 = tick();
                             D.consume(q, L[lvl].ok[sl], L[lvl].len[sl], L[lvl].cnt[sl], L[lvl].succ + sl * K, lvl + 1 < DEPTH ? &best_child : nullptr);
                             if (best_child >= 0)
                                 ans_id[n_ans] = best_child, ans_lvl[n_ans] = (uint8_t)(lvl + 1), ans_at[n_ans] = (uint8_t)at, ++n_ans;
+                            const uint64_t c1 = tick();
                             want = !q.done && D.advance(q);
+                            c_consume += c1 - c0, c_advance += tick() - c1;
                             if (!want)
                                 break;
                             // the node popped now: does the round hold its answer?
@@ -1043,6 +1080,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     else
                         want = !q.done && D.advance(q);
                     wants[qi] = want ? 1 : 0;
+                    const uint64_t c2 = tick();
                     if (want)
                     {
                         q.spec[0] = q.cur;
@@ -1057,7 +1095,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             stage[qi * KS + i] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, shoot, q.dist_start_goal_bits};
                         }
                     }
+                    c_next += tick() - c2;
                 }
+                const uint64_t c3 = tick();
                 if (hits)
                     spec_hits.fetch_add(hits, std::memory_order_relaxed);
                 if (deep)
@@ -1082,6 +1122,14 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 }
                 if (c->d_nodes && mine)
                     __builtin_ia32_sfence(); // stores into device memory leave this core's write-combining buffers
+                if (trace_on)
+                {
+                    cyc_consume.fetch_add(c_consume, std::memory_order_relaxed), cyc_advance.fetch_add(c_advance, std::memory_order_relaxed);
+                    cyc_next.fetch_add(c_next, std::memory_order_relaxed), cyc_copy.fetch_add(tick() - c3, std::memory_order_relaxed);
+                    pr_dup.fetch_add(t_probe.dup), pr_cell.fetch_add(t_probe.cell), pr_push.fetch_add(t_probe.push), pr_chain.fetch_add(t_probe.chain);
+                    pr_heads.fetch_add(t_probe.heads), pr_succ.fetch_add(t_probe.succ), pr_pushed.fetch_add(t_probe.pushed);
+                    t_probe = ConsumeProbe();
+                }
             });
             g.keep.clear();
             for (uint32_t qi : g.live)
@@ -1200,6 +1248,15 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             "open-list entries %llu, successors expanded by the deeper launches %llu (%d launches per round)\n",
                     (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)spec_hits.load(),
                     (unsigned long long)deep_hits.load(), depth_cfg);
+        if (trace_on)
+            fprintf(stderr, "hyas host threads, timestamp-counter cycles in all: taking successors %.3e, popping %.3e, choosing and staging the next nodes %.3e, "
+                            "copying them into the launch %.3e\n",
+                    (double)cyc_consume.load(), (double)cyc_advance.load(), (double)cyc_next.load(), (double)cyc_copy.load());
+        if (trace_on)
+            fprintf(stderr, "hyas taking successors: %.3e successors, duplicate check %.3e cycles (%.3e occupied buckets, %.3e open-list entries compared), "
+                            "cell lookup %.3e cycles, %.3e pushes %.3e cycles\n",
+                    (double)pr_succ.load(), (double)pr_dup.load(), (double)pr_heads.load(), (double)pr_chain.load(), (double)pr_cell.load(),
+                    (double)pr_pushed.load(), (double)pr_push.load());
         if (trace_on)
             for (int gi = 0; gi < ng; ++gi)
                 fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host %.3f s launch %.3f s wait %.3f s\n",
