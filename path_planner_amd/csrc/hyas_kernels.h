@@ -17,6 +17,9 @@ struct StepIn
     uint32_t pad;
 };
 #define STEP_DEAD 2u
+// flags of the successor role inside a search round
+#define ROUND_CHILD_SHOOT 1u   // the records written for a deeper launch ask for the analytic shot
+#define ROUND_TAG_CANDIDATE 2u // hyas_succ::pad, high byte: 1 + index of the motion-set entry (fixed motion set) the successor comes from
 
 void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
 void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
@@ -43,7 +46,8 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
                   int stats_mode, hipStream_t s, StepIn *child = nullptr, bool child_shoot = false);
 // child (optional, n records in device memory): the launch also writes, for every node, the input record of its
 // lowest-f successor (shoot = child_shoot; STEP_DEAD when the node has none), ready to be the `in` of a further launch
-// on the same stream, and marks that successor's record with pad = 1.
+// on the same stream, and marks that successor's record with bit 0 of pad.  A search round tags every successor
+// record with its motion-set entry (ROUND_TAG_CANDIDATE); hyas_expand_batch leaves pad = 0.
 // paths: concatenated poses {x, y, t}; offs: n_paths + 1 pose offsets; out_idx: offs[n_paths] + n_paths entries; out_n: n_paths
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s);
 void launch_shortcut(const DevMap &m, const float *paths, const uint32_t *offs, uint32_t n_paths, uint32_t *out_idx, uint32_t *out_n, hipStream_t s);

@@ -850,7 +850,7 @@ template <int MODE, int ADAPT>
 __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__restrict__ in, uint32_t n, const hyas_goal *__restrict__ goals,
                                             const float *__restrict__ twod, uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
                                             unsigned long long *stats, Quad *s_quads, uint32_t block, StepIn *__restrict__ child = nullptr,
-                                            uint32_t child_shoot = 0)
+                                            uint32_t flags = 0)
 {
     constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES;
     const int tid = threadIdx.x;
@@ -927,7 +927,8 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         s.idx = idx_3d(m, sx, sy, st);
         s.prim = (int8_t)prim;
         s.free = 1;
-        s.pad = 0;
+        // search rounds: which entry of the motion set this successor comes from (1-based, high byte)
+        s.pad = (flags & ROUND_TAG_CANDIDATE) ? (uint16_t)((sl + 1) << 8) : (uint16_t)0;
     }
     // compact in candidate order, as the reference's output vector
     const unsigned grp = (lane / LANES) * LANES;
@@ -937,7 +938,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     if (child)
     {
         // The successor with the lowest f = g + h (the earliest of equals: the one the open list would pop first)
-        // becomes node `slot` of the next, deeper launch; its record carries pad = 1 so that the host knows which
+        // becomes node `slot` of the next, deeper launch; its record carries bit 0 of pad so that the host knows which
         // one was taken without redoing the comparison.
         float bf = ok ? s.g + s.h : INFINITY;
         if (!(bf == bf))
@@ -952,8 +953,8 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         }
         if (ok && bi == sl)
         {
-            s.pad = 1;
-            child[slot] = StepIn{s.x, s.y, s.t, s.g, prim, node.query, child_shoot, node.pad};
+            s.pad |= 1;
+            child[slot] = StepIn{s.x, s.y, s.t, s.g, prim, node.query, flags & ROUND_CHILD_SHOOT, node.pad};
         }
         if (in_launch && seg_lane && sl == 0 && bi == 255) // nothing to expand one level down
             child[slot] = StepIn{node.x, node.y, node.t, node.g, node.prim, node.query, STEP_DEAD, node.pad};
@@ -1383,13 +1384,13 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
                                                                         const double *__restrict__ seg_tab, uint32_t seg_cap,
                                                                         uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
                                                                         uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
-                                                                        unsigned long long *stats, StepIn *__restrict__ child, uint32_t child_shoot)
+                                                                        unsigned long long *stats, StepIn *__restrict__ child, uint32_t flags)
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
     if (blockIdx.x < n) // uniform across the workgroup
         shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
     else
-        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n, child, child_shoot);
+        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n, child, flags);
 }
 
 // The accepted curves of n queries, one workgroup each: samples {x, y, t} of
@@ -2056,7 +2057,7 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
     if (m.ad_mode != 0)
         mode = 0;
     dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child,
-                                     child_shoot ? 1u : 0u, s);
+                                     (child_shoot ? ROUND_CHILD_SHOOT : 0u) | ROUND_TAG_CANDIDATE, s);
 }
 
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s)

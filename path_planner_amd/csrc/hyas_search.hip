@@ -25,13 +25,14 @@ namespace hyas
 namespace
 {
 
-#define HYAS_MAX_SPEC 8  // most open-list nodes of one query in one round
+#define HYAS_MAX_SPEC 12 // most nodes of one query in one launch: open-list entries and nodes that do not exist yet
 #define HYAS_MAX_DEPTH 4 // most launches per round: each expands the lowest-f successors of the one before
 
 struct SNode
 {
     float x, y, t, g, h;
-    int32_t prim;
+    int16_t prim;
+    int16_t cand;     // which entry of the motion set produced the node, -1 = unknown (start node, adaptive modes)
     int32_t pred;     // arena index, -1 = none (shared_ptr chain in the reference)
     int32_t dup_next; // chain of the duplicate-check hash, -1 = end
     int32_t dup_prev; // >= 0 arena index, < 0: -(bucket + 2), head of its bucket
@@ -118,8 +119,21 @@ struct Query
     int cur = -1, cur_idx = 0; // node being expanded this round
     // nodes handed to the kernel this round: spec[0] = cur, the others are the open list's next best entries,
     // expanded ahead of time in case one of them is popped right after cur
+    // Behind them: nodes that do not exist yet.  Entry i (spec[i] = -1) is the successor that motion-set entry
+    // ahead_cand[i] will produce from entry ahead_parent[i] of this list, formed on the host from the parent's pose
+    // alone (successor pose and cost depend on nothing else); its answer is used if that successor, bit for bit,
+    // is pushed and then popped during the round.
     int32_t spec[HYAS_MAX_SPEC];
-    int nspec = 0;
+    int8_t ahead_parent[HYAS_MAX_SPEC], ahead_cand[HYAS_MAX_SPEC];
+    // What this search has been doing: follow[a][b] counts how often, right after a node made by motion-set entry a,
+    // the node popped next was that node's successor by entry b; seen[a] counts the nodes made by entry a.  Only
+    // used to choose which successor to send ahead.
+    uint16_t follow[8][8] = {}, seen[8] = {};
+    // ... and how it has paid: nodes sent ahead for a parent made by entry a, how many of them were used, and how
+    // many times sending was skipped since
+    uint16_t ahead_sent[2][8] = {}, ahead_used[2][8] = {}, ahead_skipped[2][8] = {}; // [popped node / another][entry a]
+    int8_t ahead_kind[HYAS_MAX_SPEC], ahead_made_by[HYAS_MAX_SPEC];
+    int nspec = 0, n_open = 0; // nodes in the list; how many of them are open-list entries (they come first)
     int spec_w = 2; // how many of them to send next round: follows how far down the list the search has been landing
     bool shoot = false;
     bool done = false;
@@ -418,8 +432,16 @@ struct Driver
     }
 
     // Takes the kernel's answer for the node popped by advance() (:243-305).  best_child (optional): the arena index
-    // of the successor the kernel expanded one level down, -1 when that one was not pushed.
-    void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ, int32_t *best_child = nullptr)
+    // of the successor the kernel expanded one level down, -1 when that one was not pushed.  wanted (optional): the
+    // arena indices of the pushed successors that come from given motion-set entries.
+    struct Wanted // successors to report by motion-set entry: in cand[], out id[] (arena index, -1: not pushed)
+    {
+        int n = 0;
+        int cand[HYAS_MAX_SPEC];
+        int32_t id[HYAS_MAX_SPEC];
+    };
+    void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ, int32_t *best_child = nullptr,
+                 Wanted *wanted = nullptr)
     {
         const int32_t pid = q.cur;
         if (best_child)
@@ -453,7 +475,7 @@ struct Driver
         int kmin = -1;
         if (best_child)
             for (int k = 0; k < count; ++k)
-                if (succ[k].pad == 1)
+                if (succ[k].pad & 1)
                     kmin = k;
         // The reference tests, in this order: duplicate of an open-list entry, cell closed, not better than the cell's
         // g, same cell as the predecessor and beyond the tie breaker (:255-283).  Each of them only drops the
@@ -479,7 +501,7 @@ struct Driver
             t_probe.dup += p2 - p1;
             if (dup)
                 continue;
-            SNode n{s.x, s.y, s.t, s.g, s.h, (int32_t)s.prim, same_cell ? pred.pred : pid, -1, -1};
+            SNode n{s.x, s.y, s.t, s.g, s.h, (int16_t)s.prim, (int16_t)((int)(s.pad >> 8) - 1), same_cell ? pred.pred : pid, -1, -1};
             CellMap::Slot &cell = seen ? *seen : q.cells.get(iSucc);
             cell.g = n.g, cell.open = 1, cell.closed = 0;
             push(q, n, iSucc);
@@ -487,6 +509,10 @@ struct Driver
                 t_probe.push += __builtin_ia32_rdtsc() - p2, t_probe.pushed += 1;
             if (k == kmin)
                 *best_child = (int32_t)q.arena.size() - 1;
+            if (wanted)
+                for (int w = 0; w < wanted->n; ++w)
+                    if (wanted->cand[w] == n.cand)
+                        wanted->id[w] = (int32_t)q.arena.size() - 1;
         }
     }
 };
@@ -727,6 +753,19 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     if (const char *e = std::getenv("HYAS_DEPTH"))
         depth_cfg = std::min(HYAS_MAX_DEPTH, std::max(1, std::atoi(e)));
     const size_t DEPTH = (size_t)depth_cfg;
+    // Nodes sent ahead of their existence (HYAS_AHEAD, default 1 per query): a search mostly keeps the steering it
+    // has, so the successor that the popped node's own motion-set entry will produce from it (HYAS_AHEAD=2: and that
+    // successor's successor by the same entry) is formed on the host (pose and cost follow from the parent alone) and expanded
+    // in the same launch.  Fixed motion set only: the adaptive modes pick their steering from maps the host does not hold.
+    int ahead_cfg = 1;
+    if (const char *e = std::getenv("HYAS_AHEAD"))
+        ahead_cfg = std::min(4, std::max(0, std::atoi(e)));
+    if (m.ad_mode != 0)
+        ahead_cfg = 0;
+    int ahead_width = 1; // how many of a query's nodes get such successors: the popped node, the open-list entries behind it
+    if (const char *e = std::getenv("HYAS_AHEAD_WIDTH"))
+        ahead_width = std::min(4, std::max(1, std::atoi(e)));
+    ahead_width = std::min(ahead_width, ahead_cfg ? std::max(1, 4 / ahead_cfg) : 1);
     int drivers_cfg = 0;
     if (const char *e = std::getenv("HYAS_DRIVERS"))
         drivers_cfg = std::max(1, std::atoi(e));
@@ -752,8 +791,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
     auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-    const int spec_k = spec_cfg;
-    const size_t KS = (size_t)spec_k;
+    spec_cfg = std::min(spec_cfg, HYAS_MAX_SPEC - ahead_cfg * ahead_width);
+    const int spec_k = spec_cfg;                                  // open-list entries of a query in one launch, at most
+    const size_t KS = (size_t)(spec_k + ahead_cfg * ahead_width); // nodes of a query in one launch, at most
     // groups of a chunk hold ceil(cn / groups) queries each: at most cn + groups slots in all
     const size_t slots_max = cn_max + HYAS_MAX_GROUPS;
     const size_t o_in = take(slots_max * KS * sizeof(StepIn));
@@ -846,7 +886,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             Query &q = Q[i];
             const float *p = poses + 6 * i;
             q.goal = h_goal[i];
-            q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1}; // Node3D(): g = 999, prim = 0
+            q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1, -1}; // Node3D(): g = 999, prim = 0
             {
                 // Utility::GetDistance(start_, goal_), src/collisiondetection.cpp:1389
                 const float d = normf(sub(f2(p[0], p[1]), f2(q.goal.x, q.goal.y)));
@@ -979,10 +1019,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::vector<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
         std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
         const bool P_analytic = c->P.analytical_expansion != 0;
-        std::atomic<uint64_t> spec_hits{0}, deep_hits{0}, miss_child{0}, miss_other{0};
+        std::atomic<uint64_t> spec_hits{0}, deep_hits{0}, ahead_hits{0}, ahead_sent{0}, open_sent{0}, miss_child{0}, miss_other{0};
         std::atomic<uint64_t> cyc_consume{0}, cyc_advance{0}, cyc_next{0}, cyc_copy{0}; // host time by part, HYAS_TRACE only
         std::atomic<uint64_t> pr_dup{0}, pr_cell{0}, pr_push{0}, pr_chain{0}, pr_heads{0}, pr_succ{0}, pr_pushed{0};
         g_probe_on = trace_on;
+        std::vector<std::atomic<uint64_t>> probe_hist(128);
         auto tick = [trace_on]() -> uint64_t { return trace_on ? __builtin_ia32_rdtsc() : 0; };
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // where a group's results of the current round lie in the staging block (laid out for its current size)
@@ -1018,7 +1059,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             g.claim.store(0, std::memory_order_relaxed);
             gp.run_parts([&](int w) {
-                uint64_t hits = 0, deep = 0, c_consume = 0, c_advance = 0, c_next = 0;
+                uint64_t hits = 0, deep = 0, ahead = 0, n_ahead_sent = 0, n_open_sent = 0, c_consume = 0, c_advance = 0, c_next = 0;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
@@ -1028,11 +1069,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     {
                         // the nodes this round holds answers for: the open-list entries sent along (first launch) and,
                         // as they come into being, the successors that the deeper launches expanded
-                        int32_t ans_id[HYAS_MAX_SPEC * HYAS_MAX_DEPTH];
-                        uint8_t ans_lvl[HYAS_MAX_SPEC * HYAS_MAX_DEPTH], ans_at[HYAS_MAX_SPEC * HYAS_MAX_DEPTH];
+                        constexpr int ANS_CAP = 2 * HYAS_MAX_SPEC * HYAS_MAX_DEPTH;
+                        int32_t ans_id[ANS_CAP];
+                        uint8_t ans_lvl[ANS_CAP], ans_at[ANS_CAP];
                         int n_ans = 0;
                         for (int i = 1; i < q.nspec; ++i)
-                            ans_id[n_ans] = q.spec[i], ans_lvl[n_ans] = 0, ans_at[n_ans] = (uint8_t)i, ++n_ans;
+                            if (q.spec[i] >= 0)
+                                ans_id[n_ans] = q.spec[i], ans_lvl[n_ans] = 0, ans_at[n_ans] = (uint8_t)i, ++n_ans;
                         size_t lvl = 0;
                         int at = 0; // which of the query's nodes of launch `lvl` is being consumed
                         int deepest = 0;
@@ -1041,14 +1084,51 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             const size_t sl = slot0[qi] + at;
                             int32_t best_child = -1;
                             const uint64_t c0 = tick();
-                            D.consume(q, L[lvl].ok[sl], L[lvl].len[sl], L[lvl].cnt[sl], L[lvl].succ + sl * K, lvl + 1 < DEPTH ? &best_child : nullptr);
-                            if (best_child >= 0)
+                            // which of the nodes sent ahead of their existence are successors of this one
+                            Driver::Wanted wanted;
+                            int wanted_at[HYAS_MAX_SPEC];
+                            if (lvl == 0)
+                                for (int i = 1; i < q.nspec; ++i)
+                                    if (q.spec[i] < 0 && q.ahead_parent[i] == at)
+                                        wanted.cand[wanted.n] = q.ahead_cand[i], wanted.id[wanted.n] = -1, wanted_at[wanted.n] = i, ++wanted.n;
+                            D.consume(q, L[lvl].ok[sl], L[lvl].len[sl], L[lvl].cnt[sl], L[lvl].succ + sl * K, lvl + 1 < DEPTH ? &best_child : nullptr,
+                                      wanted.n ? &wanted : nullptr);
+                            if (best_child >= 0 && n_ans < ANS_CAP)
                                 ans_id[n_ans] = best_child, ans_lvl[n_ans] = (uint8_t)(lvl + 1), ans_at[n_ans] = (uint8_t)at, ++n_ans;
+                            for (int w = 0; w < wanted.n; ++w)
+                            {
+                                if (wanted.id[w] < 0 || n_ans >= ANS_CAP)
+                                    continue;
+                                // the node as the kernel produced it against the node as it was sent: the answer holds
+                                // for exactly these bits
+                                const SNode &nd = q.arena[wanted.id[w]];
+                                const StepIn &sent = stage[qi * KS + wanted_at[w]];
+                                if (std::memcmp(&nd.x, &sent.x, 4 * sizeof(float)) != 0 || (int32_t)nd.prim != sent.prim)
+                                    continue;
+                                q.spec[wanted_at[w]] = wanted.id[w];
+                                ans_id[n_ans] = wanted.id[w], ans_lvl[n_ans] = 0, ans_at[n_ans] = (uint8_t)wanted_at[w], ++n_ans;
+                            }
                             const uint64_t c1 = tick();
+                            const int32_t consumed = q.cur;
                             want = !q.done && D.advance(q);
                             c_consume += c1 - c0, c_advance += tick() - c1;
                             if (!want)
                                 break;
+                            if (ahead_cfg)
+                            {
+                                const int a = q.arena[consumed].cand, b = q.arena[q.cur].cand;
+                                if (a >= 0 && a < 8)
+                                {
+                                    if (++q.seen[a] >= 60000)
+                                    {
+                                        q.seen[a] /= 2;
+                                        for (int e = 0; e < 8; ++e)
+                                            q.follow[a][e] /= 2;
+                                    }
+                                    if (b >= 0 && b < 8 && q.arena[q.cur].pred == consumed)
+                                        ++q.follow[a][b];
+                                }
+                            }
                             // the node popped now: does the round hold its answer?
                             int j = -1;
                             for (int i = 0; i < n_ans; ++i)
@@ -1062,14 +1142,24 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                                     // an older open-list entry beyond the ones sent along
                                     bool child = false;
                                     for (int i = 0; i < q.nspec; ++i)
-                                        child = child || q.arena[q.cur].pred == q.spec[i];
+                                        if (q.spec[i] >= 0 && q.arena[q.cur].pred == q.spec[i])
+                                        {
+                                            child = true;
+                                            const int pp = q.arena[q.spec[i]].cand, cp = q.arena[q.cur].cand;
+                                            probe_hist[(i == 0 ? 0 : 1) * 64 + (pp & 7) * 8 + (cp & 7)].fetch_add(1, std::memory_order_relaxed);
+                                        }
                                     (child ? miss_child : miss_other).fetch_add(1, std::memory_order_relaxed);
                                 }
                                 break; // no: it goes to the GPU
                             }
                             lvl = ans_lvl[j], at = ans_at[j];
-                            if (lvl == 0)
+                            if (lvl == 0 && at < q.n_open)
                                 deepest = std::max(deepest, at), ++hits;
+                            else if (lvl == 0)
+                            {
+                                ++ahead;
+                                ++q.ahead_used[q.ahead_kind[at]][q.ahead_made_by[at]];
+                            }
                             else
                                 ++deep;
                         }
@@ -1086,6 +1176,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                         q.spec[0] = q.cur;
                         const int extra = spec_adapt ? std::min(q.spec_w, spec_k - 1) : spec_k - 1;
                         q.nspec = 1 + (extra > 0 ? D.next_best(q, q.spec + 1, extra) : 0);
+                        q.n_open = q.nspec;
                         for (int i = 0; i < q.nspec; ++i)
                         {
                             const SNode &nd = q.arena[q.spec[i]];
@@ -1094,6 +1185,46 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             const uint32_t shoot = i == 0 ? (q.shoot ? 1u : 0u) : (P_analytic ? 1u : 0u);
                             stage[qi * KS + i] = StepIn{nd.x, nd.y, nd.t, nd.g, nd.prim, qi, shoot, q.dist_start_goal_bits};
                         }
+                        // nodes that do not exist yet: for the popped node (and, HYAS_AHEAD_WIDTH > 1, the open-list
+                        // entries behind it) the successor by the node's own motion-set entry, that one's successor ...
+                        for (int root = 0; root < std::min(ahead_width, q.n_open); ++root)
+                        {
+                            StepIn from = stage[qi * KS + root];
+                            int parent = root, made_by = q.arena[q.spec[root]].cand;
+                            const int kind = root ? 1 : 0; // the figures of the popped node and of the others differ
+                            for (int a = 0; a < ahead_cfg && made_by >= 0 && made_by < 8 && made_by < m.n_succ; ++a)
+                            {
+                                // the entry this search has followed most often after a node made by `made_by`; the
+                                // same entry again until there is something to go by
+                                int entry = made_by;
+                                if (q.seen[made_by] >= 16)
+                                    for (int e = 0; e < m.n_succ && e < 8; ++e)
+                                        if (q.follow[made_by][e] > 2 * q.follow[made_by][entry])
+                                            entry = e;
+                                // not worth a place in the launch when fewer than one in eight has been used; every
+                                // sixteenth time it is sent all the same, so that the figures keep up with the search
+                                if (q.ahead_sent[kind][made_by] >= 32 &&
+                                    (uint32_t)q.ahead_used[kind][made_by] * 8u < (uint32_t)q.ahead_sent[kind][made_by] &&
+                                    (++q.ahead_skipped[kind][made_by] & 15) != 0)
+                                    break;
+                                if (++q.ahead_sent[kind][made_by] >= 60000)
+                                    q.ahead_sent[kind][made_by] /= 2, q.ahead_used[kind][made_by] /= 2;
+                                const float dist = normf(sub(f2(from.x, from.y), f2(q.goal.x, q.goal.y)));
+                                float sx, sy, st;
+                                int prim;
+                                if (!successor_pose(m, from.x, from.y, from.t, dist, entry, sx, sy, st, prim))
+                                    break;
+                                const float step = normf(sub(f2(sx, sy), f2(from.x, from.y)));
+                                const StepIn next{sx, sy, st, cost_so_far(m, from.g, step, prim, from.prim), prim, qi, P_analytic ? 1u : 0u,
+                                                  q.dist_start_goal_bits};
+                                const int i = q.nspec++;
+                                q.spec[i] = -1, q.ahead_parent[i] = (int8_t)parent, q.ahead_cand[i] = (int8_t)entry;
+                                q.ahead_kind[i] = (int8_t)kind, q.ahead_made_by[i] = (int8_t)made_by;
+                                stage[qi * KS + i] = next;
+                                from = next, parent = i, made_by = entry;
+                            }
+                        }
+                        n_open_sent += (uint64_t)q.n_open - 1, n_ahead_sent += (uint64_t)(q.nspec - q.n_open);
                     }
                     c_next += tick() - c2;
                 }
@@ -1102,6 +1233,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     spec_hits.fetch_add(hits, std::memory_order_relaxed);
                 if (deep)
                     deep_hits.fetch_add(deep, std::memory_order_relaxed);
+                if (ahead)
+                    ahead_hits.fetch_add(ahead, std::memory_order_relaxed);
+                if (trace_on)
+                    ahead_sent.fetch_add(n_ahead_sent, std::memory_order_relaxed), open_sent.fetch_add(n_open_sent, std::memory_order_relaxed);
                 // This worker's nodes go into a range of the launch it claims in one step, copied by the thread
                 // that has just written them (one thread gathering everybody's nodes would fetch each line from
                 // another core's cache).  The order of the nodes within a launch is immaterial: results are found
@@ -1245,13 +1380,29 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
 
         if (trace_on)
             fprintf(stderr, "hyas rounds ended by: a successor of a node of the same round %llu, an older open-list entry %llu; answered ahead: "
-                            "open-list entries %llu, successors expanded by the deeper launches %llu (%d launches per round)\n",
+                            "open-list entries %llu of %llu sent, nodes sent ahead of their existence %llu of %llu (at most %d per query), successors expanded "
+                            "by the deeper launches %llu (%d launches per round)\n",
                     (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)spec_hits.load(),
+                    (unsigned long long)open_sent.load(), (unsigned long long)ahead_hits.load(), (unsigned long long)ahead_sent.load(), ahead_cfg,
                     (unsigned long long)deep_hits.load(), depth_cfg);
         if (trace_on)
             fprintf(stderr, "hyas host threads, timestamp-counter cycles in all: taking successors %.3e, popping %.3e, choosing and staging the next nodes %.3e, "
                             "copying them into the launch %.3e\n",
                     (double)cyc_consume.load(), (double)cyc_advance.load(), (double)cyc_next.load(), (double)cyc_copy.load());
+        if (trace_on)
+            for (int a = 0; a < 2; ++a)
+                for (int pp = 0; pp < 8; ++pp)
+                {
+                    uint64_t row = 0;
+                    for (int cp = 0; cp < 8; ++cp)
+                        row += probe_hist[a * 64 + pp * 8 + cp].load();
+                    if (!row)
+                        continue;
+                    fprintf(stderr, "hyas round-ending successor of %s, parent's motion-set entry %d: by own motion-set entry", a ? "another node of the round" : "the round's first node", pp);
+                    for (int cp = 0; cp < 8; ++cp)
+                        fprintf(stderr, " %llu", (unsigned long long)probe_hist[a * 64 + pp * 8 + cp].load());
+                    fprintf(stderr, "\n");
+                }
         if (trace_on)
             fprintf(stderr, "hyas taking successors: %.3e successors, duplicate check %.3e cycles (%.3e occupied buckets, %.3e open-list entries compared), "
                             "cell lookup %.3e cycles, %.3e pushes %.3e cycles\n",

@@ -148,7 +148,7 @@ def test_large_map_query_blocks(oracle_built):
 
 def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
     """How the host schedules the search (query groups in flight, worker threads, nodes expanded ahead of time per
-    query, launches per round, chunk size) must not show in any output: result records, expansion order and paths are bit-identical."""
+    query, nodes sent ahead of their existence, launches per round, chunk size) must not show in any output: result records, expansion order and paths are bit-identical."""
     h = maze_ctx
     S, G = make_queries(h.collision, 300, 77, 50, 50)
     base = h.plan_batch(S, G)
@@ -161,9 +161,11 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
                 dict(HYAS_SPEC="5", HYAS_SPEC_FLOOR="0", HYAS_DRIVERS="8"),
                 dict(HYAS_DEPTH="1"), dict(HYAS_DEPTH="2"), dict(HYAS_DEPTH="3", HYAS_SPEC="3"), dict(HYAS_DEPTH="4", HYAS_SPEC="1", HYAS_GROUPS="2"),
                 dict(HYAS_DEPTH="2", HYAS_CHUNK="97", HYAS_NODES_IN_HOST_MEMORY="1"),
+                dict(HYAS_AHEAD="0"), dict(HYAS_AHEAD="1", HYAS_SPEC="1"), dict(HYAS_AHEAD="4", HYAS_SPEC="8"), dict(HYAS_AHEAD="3", HYAS_DEPTH="2"),
+                dict(HYAS_AHEAD="1", HYAS_AHEAD_WIDTH="4"), dict(HYAS_AHEAD="2", HYAS_AHEAD_WIDTH="2", HYAS_SPEC="8"),
                 dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"), dict()):
         for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS",
-                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH"):
+                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
