@@ -519,13 +519,56 @@ struct Driver
 
 // Minimal fork-join pool: the calling thread takes part, workers spin between
 // rounds (a round lasts tens of microseconds).
+// Worker threads stay on one CPU each (a query is always handled by the same thread: its heap, cell map and
+// duplicate hash then stay in that core's cache), neighbours in a pool on neighbouring CPUs of the process's affinity
+// mask; the ranks of a node take consecutive runs of CPUs.  Off when the mask holds fewer CPUs than the ranks'
+// threads together, or with HYAS_PIN=0.
+static int local_rank_env(const char *name)
+{
+    const char *e = std::getenv(name);
+    return e ? std::max(0, std::atoi(e)) : 0;
+}
+static bool pinning_on(int threads_in_all)
+{
+    if (const char *e = std::getenv("HYAS_PIN"))
+        if (std::atoi(e) == 0)
+            return false;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) != 0)
+        return false;
+    const int ranks = std::max(1, local_rank_env("LOCAL_WORLD_SIZE"));
+    return CPU_COUNT(&set) >= ranks * threads_in_all;
+}
+static void pin_self(int index, int threads_in_all)
+{
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) != 0)
+        return;
+    std::vector<int> cpus;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &set))
+            cpus.push_back(c);
+    if (cpus.empty())
+        return;
+    const size_t at = (size_t)local_rank_env("LOCAL_RANK") * (size_t)threads_in_all + (size_t)index;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpus[at % cpus.size()], &one);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+}
+
 class Pool
 {
   public:
-    explicit Pool(int nthreads) : n_(std::max(1, nthreads))
+    // first_cpu >= 0: thread i stays on CPU number first_cpu + i of the `pin_total` this rank uses
+    explicit Pool(int nthreads, int first_cpu = -1, int pin_total = 0) : n_(std::max(1, nthreads)), first_cpu_(first_cpu)
     {
         for (int i = 1; i < n_; ++i)
-            th_.emplace_back([this, i] { worker(i); });
+            th_.emplace_back([this, i, pin_total] {
+                if (first_cpu_ >= 0)
+                    pin_self(first_cpu_ + i, pin_total);
+                worker(i);
+            });
     }
     int size() const { return n_; }
     ~Pool()
@@ -625,7 +668,7 @@ class Pool
             pending_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
-    int n_;
+    int n_, first_cpu_;
     std::vector<std::thread> th_;
     std::atomic<uint64_t> gen_{0};
     std::atomic<bool> stop_{false};
@@ -678,12 +721,15 @@ struct SearchPools
         return *main;
     }
     // n pools of `threads` threads each
+    bool pinned = false;
+    int pin_total = 0;
     void driver_pools(int n, int threads)
     {
-        if (driver_threads != threads)
-            driver.clear(), driver_threads = threads;
+        const bool pin = pinning_on(n * threads);
+        if (driver_threads != threads || pinned != pin || (pin && pin_total != n * threads))
+            driver.clear(), driver_threads = threads, pinned = pin, pin_total = n * threads;
         while ((int)driver.size() < n)
-            driver.emplace_back(new Pool(threads));
+            driver.emplace_back(new Pool(threads, pin ? (int)driver.size() * threads : -1, pin_total));
     }
 };
 
@@ -1332,6 +1378,20 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 return;
             }
             Pool &gp = *c->pools->driver[d];
+            cpu_set_t before;
+            const bool pinned = c->pools->pinned && pthread_getaffinity_np(pthread_self(), sizeof before, &before) == 0;
+            if (pinned)
+                pin_self(d * gp.size(), c->pools->pin_total);
+            struct Unpin // the calling thread drives group 0: it gets its own mask back
+            {
+                bool on;
+                cpu_set_t *set;
+                ~Unpin()
+                {
+                    if (on)
+                        (void)pthread_setaffinity_np(pthread_self(), sizeof *set, set);
+                }
+            } unpin{pinned, &before};
             bool inflight[HYAS_MAX_GROUPS] = {false};
             for (int gi = d; gi < ng; gi += n_drivers)
                 if (host_round(G[gi], gp, false))
