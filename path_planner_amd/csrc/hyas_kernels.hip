@@ -994,7 +994,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
 // colliding one (what a serial scan tests), 2 obstacle-list entries behind (1),
 // 7 shots; (MODE 2) shader-clock sums: 8 phases 1+2, 9 interpolation,
 // 10 collision tests, 11..14 time from the start to: frame normalised, candidates evaluated, winner known, prefix
-// stored; 15 arrival of node and goal, 16 whole workgroup, 17 / 18 pose / swept-segment tests of waves 0 / 2,
+// stored; 15 arrival of node and goal, 16 whole workgroup, 17 / 18 tests of wave 0 (pose tests in even rounds) / wave 2,
 // 6 workgroups, 19 sample passes.
 template <int MODE, int CURVE>
 __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restrict__ in, const hyas_goal *__restrict__ goals,
@@ -1251,13 +1251,15 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             c2 = clock64();
             t_interp += c2 - c1, ++n_batches;
         }
-        // two test rounds: the first half of the workgroup runs the pose tests, the second half the swept-segment tests;
-        // the workgroup meets once, after both (in between, the flag alone tells a lane that the shot is decided)
+        // two test rounds: one half of the workgroup runs the pose tests, the other half the swept-segment tests, and
+        // the halves change roles for the second round (a swept-segment test takes about 1.4 times a pose test: both
+        // halves then finish together); the workgroup meets once, after both (in between, the flag alone tells a
+        // lane that the shot is decided)
         for (int half = 0; half < SHOT_BATCH / (SHOT_THREADS / 2); ++half)
         {
             const uint32_t j = half * (SHOT_THREADS / 2) + (tid & (SHOT_THREADS / 2 - 1)); // sample inside the batch
             const uint32_t k = base + j;
-            const bool pose_lane = tid < SHOT_THREADS / 2;
+            const bool pose_lane = (tid < SHOT_THREADS / 2) != ((half & 1) != 0);
             if (base + half * (SHOT_THREADS / 2) >= nsamp)
                 break;
             if (STATS && tid == 0)
@@ -1337,7 +1339,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             atomicAdd(&stats[11], (unsigned long long)mk0), atomicAdd(&stats[12], (unsigned long long)mk1);
             atomicAdd(&stats[13], (unsigned long long)mk2), atomicAdd(&stats[14], (unsigned long long)mk3);
         }
-        if (lane == 0 && (wave == 0 || wave == 2)) // pose tests of wave 0, swept-segment tests of wave 2
+        if (lane == 0 && (wave == 0 || wave == 2)) // tests of wave 0 (pose tests first) and of wave 2 (swept-segment tests first)
             atomicAdd(&stats[17 + wave / 2], (unsigned long long)t_test);
         if (tid == 0)
         {
