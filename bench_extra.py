@@ -4,7 +4,8 @@
                    per GPU per step, poses resident in HBM;
  rs_table          Reeds-Shepp heuristic table of a 180 x 60 map (rho 0.35), heading slices sharded over the
                    GPUs and assembled with one all-gather, then installed on every GPU;
- queries_large     65 536 planning queries on maps/map_large sharded over the GPUs (strong scaling).
+ queries_large     65 536 planning queries on maps/map_large sharded over the GPUs (strong scaling);
+ single_query      the maze queries one per call, as the reference's makePlan hands them over: latency per query.
 
 Same output contract as bench.py: one JSON line on rank 0.
 """
@@ -266,8 +267,52 @@ def queries_large(args):
     }
 
 
+def single_query(args):
+    """One query per hyas_plan_batch call (HybridAStarPlanner::makePlan, src/hybrid_a_star_planner.cpp:99-124, plans one
+    start/goal pair per call): a step is one pass over the first 64 benchmark queries of every GPU, one after the other."""
+    torch, dist, rank, local_rank, world = _dist_setup()
+    from path_planner_amd import Hyas, hot_path_params
+    from path_planner_amd.sharding import aggregate, load_map, make_queries
+
+    mp = load_map("map_maze")
+    ctx = Hyas(hot_path_params(), device=local_rank)
+    ctx.set_costmap(mp, build_table=True)
+    nq = 64 if args.queries == 1024 else args.queries
+    starts, goals = make_queries(ctx.collision, nq, 20250228 + 7919 * rank, 50, 50)
+    for _ in range(args.warmup):
+        ctx.plan_batch(starts[:1], goals[:1])
+    _barrier(torch, dist)
+    lat = []
+    succ = expd = launches = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for i in range(nq):
+            t1 = time.perf_counter()
+            r = ctx.plan_batch(starts[i:i + 1], goals[i:i + 1])
+            lat.append(time.perf_counter() - t1)
+            succ += int(r["successors"][0])
+            expd += int(r["nodes_expanded"][0])
+            launches += ctx.kernel_ms(0)[1]
+    _barrier(torch, dist)
+    local_s = time.perf_counter() - t0
+    total_s, (succ, expd, n_done, launches) = aggregate(dist, local_s, [float(succ), float(expd), float(nq * args.steps), float(launches)])
+    if rank != 0:
+        return None
+    lat = np.array(lat) * 1e3
+    return {
+        "metric": "collision-checked node expansions/sec", "value": succ / total_s, "unit": "successors/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"map_maze 50x50, {nq} queries per GPU, one query per call, Reeds-Shepp shot every pop"},
+        "queries_per_s": n_done / total_s, "nodes_expanded_per_s": expd / total_s,
+        "latency_ms_rank0": {"mean": float(lat.mean()), "median": float(np.median(lat)), "p90": float(np.percentile(lat, 90)), "max": float(lat.max())},
+        "rounds_per_query": launches / n_done, "expansions_per_round": expd / max(launches, 1.0),
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
 def run(args):
-    fn = {"footprint_checks": footprint_checks, "footprint_checks_car": lambda a: footprint_checks(a, "car"), "rs_table": rs_table,
+    fn = {"single_query": single_query, "footprint_checks": footprint_checks, "footprint_checks_car": lambda a: footprint_checks(a, "car"), "rs_table": rs_table,
           "queries_large": queries_large}[args.workload]
     line = fn(args)
     if line is not None:

@@ -25,7 +25,9 @@ namespace hyas
 namespace
 {
 
-#define HYAS_MAX_SPEC 12 // most nodes of one query in one launch: open-list entries and nodes that do not exist yet
+#define HYAS_MAX_SPEC 24   // most open-list entries of one query in one launch
+#define HYAS_MAX_TREE 100  // most nodes of one query in one launch that do not exist yet
+#define HYAS_MAX_NODES 124 // most nodes of one query in one launch
 #define HYAS_MAX_DEPTH 4 // most launches per round: each expands the lowest-f successors of the one before
 
 struct SNode
@@ -123,8 +125,8 @@ struct Query
     // ahead_cand[i] will produce from entry ahead_parent[i] of this list, formed on the host from the parent's pose
     // alone (successor pose and cost depend on nothing else); its answer is used if that successor, bit for bit,
     // is pushed and then popped during the round.
-    int32_t spec[HYAS_MAX_SPEC];
-    int8_t ahead_parent[HYAS_MAX_SPEC], ahead_cand[HYAS_MAX_SPEC];
+    int32_t spec[HYAS_MAX_NODES];
+    int8_t ahead_parent[HYAS_MAX_NODES], ahead_cand[HYAS_MAX_NODES];
     // What this search has been doing: follow[a][b] counts how often, right after a node made by motion-set entry a,
     // the node popped next was that node's successor by entry b; seen[a] counts the nodes made by entry a.  Only
     // used to choose which successor to send ahead.
@@ -132,7 +134,7 @@ struct Query
     // ... and how it has paid: nodes sent ahead for a parent made by entry a, how many of them were used, and how
     // many times sending was skipped since
     uint16_t ahead_sent[2][8] = {}, ahead_used[2][8] = {}, ahead_skipped[2][8] = {}; // [popped node / another][entry a]
-    int8_t ahead_kind[HYAS_MAX_SPEC], ahead_made_by[HYAS_MAX_SPEC];
+    int8_t ahead_kind[HYAS_MAX_NODES], ahead_made_by[HYAS_MAX_NODES];
     int nspec = 0, n_open = 0; // nodes in the list; how many of them are open-list entries (they come first)
     int spec_w = 2; // how many of them to send next round: follows how far down the list the search has been landing
     bool shoot = false;
@@ -437,8 +439,8 @@ struct Driver
     struct Wanted // successors to report by motion-set entry: in cand[], out id[] (arena index, -1: not pushed)
     {
         int n = 0;
-        int cand[HYAS_MAX_SPEC];
-        int32_t id[HYAS_MAX_SPEC];
+        int cand[HYAS_MAX_NODES];
+        int32_t id[HYAS_MAX_NODES];
     };
     void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ, int32_t *best_child = nullptr,
                  Wanted *wanted = nullptr)
@@ -786,9 +788,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // A query sends fewer extra nodes while its speculation is not paying off: two beyond the deepest entry the
     // search used last round, one less (down to HYAS_SPEC_FLOOR) after a round that used none.  HYAS_SPEC_ADAPT=0
     // sends the full width every round.
-    const bool spec_adapt = !(std::getenv("HYAS_SPEC_ADAPT") && std::atoi(std::getenv("HYAS_SPEC_ADAPT")) == 0);
+    // A call with a handful of queries (the plugin's makePlan: one) leaves the GPU idle whatever is sent: the full
+    // width every round then, sixteen open-list entries and the popped node's neighbourhood (HYAS_TREE below):
+    // 27.0 instead of 46.9 ms per maze query, one query per call.
+    const bool few_queries = n <= 32;
+    const bool spec_adapt = std::getenv("HYAS_SPEC_ADAPT") ? std::atoi(std::getenv("HYAS_SPEC_ADAPT")) != 0 : !few_queries;
     const int spec_floor = std::getenv("HYAS_SPEC_FLOOR") ? std::max(0, std::atoi(std::getenv("HYAS_SPEC_FLOOR"))) : 2;
-    int spec_cfg = 6;
+    int spec_cfg = few_queries ? 16 : 6;
     if (const char *e = std::getenv("HYAS_SPEC"))
         spec_cfg = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
     // Launches per round.  The second launch expands, for every node of the first, its lowest-f successor (which the
@@ -803,7 +809,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // has, so the successor that the popped node's own motion-set entry will produce from it (HYAS_AHEAD=2: and that
     // successor's successor by the same entry) is formed on the host (pose and cost follow from the parent alone) and expanded
     // in the same launch.  Fixed motion set only: the adaptive modes pick their steering from maps the host does not hold.
-    int ahead_cfg = 1;
+    int ahead_cfg = few_queries ? 2 : 1;
     if (const char *e = std::getenv("HYAS_AHEAD"))
         ahead_cfg = std::min(4, std::max(0, std::atoi(e)));
     if (m.ad_mode != 0)
@@ -812,6 +818,15 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     if (const char *e = std::getenv("HYAS_AHEAD_WIDTH"))
         ahead_width = std::min(4, std::max(1, std::atoi(e)));
     ahead_width = std::min(ahead_width, ahead_cfg ? std::max(1, 4 / ahead_cfg) : 1);
+    // With a handful of queries the launch has room for the popped node's whole neighbourhood (HYAS_TREE nodes, 0-100,
+    // default 48 then, else 0): its successors by every motion-set entry, their successors, ... breadth first, each
+    // node's own entry first.  Takes the place of the single successors above.
+    int tree_cfg = few_queries ? 48 : 0;
+    if (const char *e = std::getenv("HYAS_TREE"))
+        tree_cfg = std::min(HYAS_MAX_TREE, std::max(0, std::atoi(e)));
+    if (m.ad_mode != 0)
+        tree_cfg = 0;
+    const int ahead_nodes = tree_cfg ? tree_cfg : ahead_cfg * ahead_width; // nodes of a query that do not exist yet, at most
     int drivers_cfg = 0;
     if (const char *e = std::getenv("HYAS_DRIVERS"))
         drivers_cfg = std::max(1, std::atoi(e));
@@ -837,9 +852,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
     auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-    spec_cfg = std::min(spec_cfg, HYAS_MAX_SPEC - ahead_cfg * ahead_width);
-    const int spec_k = spec_cfg;                                  // open-list entries of a query in one launch, at most
-    const size_t KS = (size_t)(spec_k + ahead_cfg * ahead_width); // nodes of a query in one launch, at most
+    const int spec_k = spec_cfg;                      // open-list entries of a query in one launch, at most
+    const size_t KS = (size_t)(spec_k + ahead_nodes); // nodes of a query in one launch, at most
+    static_assert(HYAS_MAX_SPEC + HYAS_MAX_TREE <= HYAS_MAX_NODES && HYAS_MAX_NODES <= 127, "positions are kept in int8_t");
     // groups of a chunk hold ceil(cn / groups) queries each: at most cn + groups slots in all
     const size_t slots_max = cn_max + HYAS_MAX_GROUPS;
     const size_t o_in = take(slots_max * KS * sizeof(StepIn));
@@ -1115,7 +1130,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     {
                         // the nodes this round holds answers for: the open-list entries sent along (first launch) and,
                         // as they come into being, the successors that the deeper launches expanded
-                        constexpr int ANS_CAP = 2 * HYAS_MAX_SPEC * HYAS_MAX_DEPTH;
+                        constexpr int ANS_CAP = 2 * HYAS_MAX_NODES * HYAS_MAX_DEPTH;
                         int32_t ans_id[ANS_CAP];
                         uint8_t ans_lvl[ANS_CAP], ans_at[ANS_CAP];
                         int n_ans = 0;
@@ -1132,7 +1147,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             const uint64_t c0 = tick();
                             // which of the nodes sent ahead of their existence are successors of this one
                             Driver::Wanted wanted;
-                            int wanted_at[HYAS_MAX_SPEC];
+                            int wanted_at[HYAS_MAX_NODES];
                             if (lvl == 0)
                                 for (int i = 1; i < q.nspec; ++i)
                                     if (q.spec[i] < 0 && q.ahead_parent[i] == at)
@@ -1233,6 +1248,38 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                         }
                         // nodes that do not exist yet: for the popped node (and, HYAS_AHEAD_WIDTH > 1, the open-list
                         // entries behind it) the successor by the node's own motion-set entry, that one's successor ...
+                        if (tree_cfg)
+                        {
+                            // breadth first from the popped node; a parent's own motion-set entry comes first
+                            int8_t queue[HYAS_MAX_NODES];
+                            int head = 0, tail = 0;
+                            queue[tail++] = 0;
+                            const int limit = q.n_open + tree_cfg;
+                            while (head < tail && q.nspec < limit)
+                            {
+                                const int parent = queue[head++];
+                                const StepIn from = stage[qi * KS + parent];
+                                const int own = parent == 0 ? (int)q.arena[q.cur].cand : (int)q.ahead_cand[parent];
+                                const float dist = normf(sub(f2(from.x, from.y), f2(q.goal.x, q.goal.y)));
+                                for (int j = 0; j < m.n_succ && q.nspec < limit; ++j)
+                                {
+                                    // order: own entry, then the others as the motion set lists them
+                                    const int entry = own >= 0 && own < m.n_succ ? (j == 0 ? own : (j <= own ? j - 1 : j)) : j;
+                                    float sx, sy, st;
+                                    int prim;
+                                    if (!successor_pose(m, from.x, from.y, from.t, dist, entry, sx, sy, st, prim))
+                                        continue;
+                                    const float step = normf(sub(f2(sx, sy), f2(from.x, from.y)));
+                                    const int i = q.nspec++;
+                                    q.spec[i] = -1, q.ahead_parent[i] = (int8_t)parent, q.ahead_cand[i] = (int8_t)entry;
+                                    q.ahead_kind[i] = 0, q.ahead_made_by[i] = (int8_t)(own >= 0 && own < 8 ? own : 0);
+                                    stage[qi * KS + i] = StepIn{sx, sy, st, cost_so_far(m, from.g, step, prim, from.prim), prim, qi, P_analytic ? 1u : 0u,
+                                                                q.dist_start_goal_bits};
+                                    queue[tail++] = (int8_t)i;
+                                }
+                            }
+                        }
+                        else
                         for (int root = 0; root < std::min(ahead_width, q.n_open); ++root)
                         {
                             StepIn from = stage[qi * KS + root];
