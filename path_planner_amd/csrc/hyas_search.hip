@@ -788,13 +788,16 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // A query sends fewer extra nodes while its speculation is not paying off: two beyond the deepest entry the
     // search used last round, one less (down to HYAS_SPEC_FLOOR) after a round that used none.  HYAS_SPEC_ADAPT=0
     // sends the full width every round.
-    // A call with a handful of queries (the plugin's makePlan: one) leaves the GPU idle whatever is sent: the full
-    // width every round then, sixteen open-list entries and the popped node's neighbourhood (HYAS_TREE below):
-    // 27.0 instead of 46.9 ms per maze query, one query per call.
-    const bool few_queries = n <= 32;
+    // The fewer queries a call brings (the plugin's makePlan: one), the more room a launch has for nodes of each: about
+    // 5600 nodes per round over all queries is what the GPU takes before the rounds get longer faster than they get
+    // fewer (measured on maze batches of 1 to 1024 queries).  Per query: at most 64 nodes -- 16 open-list entries and
+    // the popped node's neighbourhood (HYAS_TREE below), 27.0 instead of 46.9 ms for one maze query per call -- down
+    // to the 6 + 1 of large batches; below 11 per query the width follows each query's recent use, above it is fixed.
+    const int per_query = (int)std::min<size_t>(64, std::max<size_t>(7, 5632 / std::max<size_t>(n, 1)));
+    const bool few_queries = per_query >= 11;
     const bool spec_adapt = std::getenv("HYAS_SPEC_ADAPT") ? std::atoi(std::getenv("HYAS_SPEC_ADAPT")) != 0 : !few_queries;
     const int spec_floor = std::getenv("HYAS_SPEC_FLOOR") ? std::max(0, std::atoi(std::getenv("HYAS_SPEC_FLOOR"))) : 2;
-    int spec_cfg = few_queries ? 16 : 6;
+    int spec_cfg = few_queries ? std::min(16, 4 + (per_query + 2) / 5) : 6;
     if (const char *e = std::getenv("HYAS_SPEC"))
         spec_cfg = std::min(HYAS_MAX_SPEC, std::max(1, std::atoi(e)));
     // Launches per round.  The second launch expands, for every node of the first, its lowest-f successor (which the
@@ -819,9 +822,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         ahead_width = std::min(4, std::max(1, std::atoi(e)));
     ahead_width = std::min(ahead_width, ahead_cfg ? std::max(1, 4 / ahead_cfg) : 1);
     // With a handful of queries the launch has room for the popped node's whole neighbourhood (HYAS_TREE nodes, 0-100,
-    // default 48 then, else 0): its successors by every motion-set entry, their successors, ... breadth first, each
+    // default: what the call's per-query share leaves beside the open-list entries, 48 at most): its successors by every motion-set entry, their successors, ... breadth first, each
     // node's own entry first.  Takes the place of the single successors above.
-    int tree_cfg = few_queries ? 48 : 0;
+    int tree_cfg = few_queries ? per_query - spec_cfg : 0;
     if (const char *e = std::getenv("HYAS_TREE"))
         tree_cfg = std::min(HYAS_MAX_TREE, std::max(0, std::atoi(e)));
     if (m.ad_mode != 0)
