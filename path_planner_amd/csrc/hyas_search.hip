@@ -834,7 +834,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     if (const char *e = std::getenv("HYAS_DRIVERS"))
         drivers_cfg = std::max(1, std::atoi(e));
     const bool trace_on = std::getenv("HYAS_TRACE") != nullptr;
-    const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : 1;
+    // rounds between the pairs of timing events behind hyas_kernel_ms (the figure is scaled up from the timed launches):
+    // every round for large calls, every 16th where a round is short enough for two event records to show
+    const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : (n <= 64 ? 16 : 1);
     std::vector<float> shot_buf;
     // a failed HIP call may leave kernels of other groups in flight that write into the staging block: wait for them
     auto drain = [&](int rc) {
