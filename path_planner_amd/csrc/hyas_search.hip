@@ -28,6 +28,8 @@ namespace
 #define HYAS_MAX_SPEC 24   // most open-list entries of one query in one launch
 #define HYAS_MAX_TREE 100  // most nodes of one query in one launch that do not exist yet
 #define HYAS_MAX_NODES 124 // most nodes of one query in one launch
+static size_t ROUND_NODES = 2048; // nodes per round over all queries of a call that the widths aim at
+constexpr int SHARE_MIN = 7, SHARE_MAX = 64, SHARE_FIXED = 11; // a query's share of them: least, most, fixed widths from here up
 #define HYAS_MAX_DEPTH 4 // most launches per round: each expands the lowest-f successors of the one before
 
 struct SNode
@@ -793,8 +795,17 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // fewer (measured on maze batches of 1 to 1024 queries).  Per query: at most 64 nodes -- 16 open-list entries and
     // the popped node's neighbourhood (HYAS_TREE below), 27.0 instead of 46.9 ms for one maze query per call -- down
     // to the 6 + 1 of large batches; below 11 per query the width follows each query's recent use, above it is fixed.
-    const int per_query = (int)std::min<size_t>(64, std::max<size_t>(7, 5632 / std::max<size_t>(n, 1)));
-    const bool few_queries = per_query >= 11;
+    // The share is worked out again every round from the queries still alive (a batch thins out as its searches end:
+    // the benchmark batch spends most of its rounds with a quarter of its queries), unless one of HYAS_SPEC,
+    // HYAS_SPEC_ADAPT, HYAS_AHEAD, HYAS_AHEAD_WIDTH, HYAS_TREE fixes the widths for the whole call.
+    auto share_of = [](size_t queries) { return (int)std::min<size_t>(SHARE_MAX, std::max<size_t>(SHARE_MIN, ROUND_NODES / std::max<size_t>(queries, 1))); };
+    if (const char *e = std::getenv("HYAS_ROUND_NODES"))
+        ROUND_NODES = (size_t)std::max(64, std::atoi(e));
+    const bool widths_follow_live = !(std::getenv("HYAS_SPEC") || std::getenv("HYAS_SPEC_ADAPT") || std::getenv("HYAS_AHEAD") ||
+                                      std::getenv("HYAS_AHEAD_WIDTH") || std::getenv("HYAS_TREE") ||
+                                      (std::getenv("HYAS_LIVE_WIDTHS") && std::atoi(std::getenv("HYAS_LIVE_WIDTHS")) == 0));
+    const int per_query = share_of(n);
+    const bool few_queries = per_query >= SHARE_FIXED;
     const bool spec_adapt = std::getenv("HYAS_SPEC_ADAPT") ? std::atoi(std::getenv("HYAS_SPEC_ADAPT")) != 0 : !few_queries;
     const int spec_floor = std::getenv("HYAS_SPEC_FLOOR") ? std::max(0, std::atoi(std::getenv("HYAS_SPEC_FLOOR"))) : 2;
     int spec_cfg = few_queries ? std::min(16, 4 + (per_query + 2) / 5) : 6;
@@ -857,14 +868,22 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
     auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
-    const int spec_k = spec_cfg;                      // open-list entries of a query in one launch, at most
-    const size_t KS = (size_t)(spec_k + ahead_nodes); // nodes of a query in one launch, at most
+    const int spec_k = spec_cfg; // open-list entries of a query in one launch, at most (widths fixed for the call)
+    // nodes of a query in one launch, at most
+    const size_t KS = widths_follow_live ? (size_t)SHARE_MAX : (size_t)(spec_k + ahead_nodes);
+    // nodes of one group of a chunk in one launch, at most: with widths that follow the live queries, SHARE_MIN each
+    // while the group is full, its part of ROUND_NODES (rounded up by one query's share) once it has thinned out
+    auto group_slots = [&](size_t gcap_, size_t ng_) {
+        return widths_follow_live ? std::max<size_t>(SHARE_MIN * gcap_, ROUND_NODES / ng_ + SHARE_MAX) : gcap_ * KS;
+    };
     static_assert(HYAS_MAX_SPEC + HYAS_MAX_TREE <= HYAS_MAX_NODES && HYAS_MAX_NODES <= 127, "positions are kept in int8_t");
     // groups of a chunk hold ceil(cn / groups) queries each: at most cn + groups slots in all
     const size_t slots_max = cn_max + HYAS_MAX_GROUPS;
-    const size_t o_in = take(slots_max * KS * sizeof(StepIn));
-    const size_t o_succ = take(DEPTH * (res_stride(slots_max * KS) + HYAS_MAX_GROUPS * 512));
-    const size_t child_stride = (slots_max * KS * sizeof(StepIn) + 255) & ~(size_t)255; // device side only
+    // nodes of all groups together, at most (the sum of group_slots over any split into at most HYAS_MAX_GROUPS groups)
+    const size_t nodes_max = widths_follow_live ? SHARE_MIN * slots_max + ROUND_NODES + (size_t)SHARE_MAX * HYAS_MAX_GROUPS : slots_max * KS;
+    const size_t o_in = take(nodes_max * sizeof(StepIn));
+    const size_t o_succ = take(DEPTH * (res_stride(nodes_max) + HYAS_MAX_GROUPS * 512));
+    const size_t child_stride = (nodes_max * sizeof(StepIn) + 255) & ~(size_t)255; // device side only
     const size_t o_child = take((DEPTH - 1) * child_stride + 256);
     // set-up staging, per buffer set: goals, poses {start, goal}, relative poses for the table lookup, their results
     struct PrepOff
@@ -889,7 +908,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
     // the popped nodes go into device memory the host can store into, where there is such memory, else into the
     // pinned host block; r_in: where the host writes them, k_in: where the kernel reads them
-    if ((rc = ensure_nodes(c, slots_max * KS * sizeof(StepIn))) != HYAS_OK)
+    if ((rc = ensure_nodes(c, nodes_max * sizeof(StepIn))) != HYAS_OK)
         return rc;
     StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
     const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
@@ -1054,6 +1073,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         const size_t want_groups = n_groups ? n_groups : (cn <= 2048 ? 4 : 8);
         const int ng = (int)std::max<size_t>(1, std::min<size_t>(want_groups, cn / 32 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
+        const size_t gslots = group_slots(gcap, (size_t)ng); // node slots per group
         const int max_drivers = drivers_cfg ? drivers_cfg : std::max(1, ng / 2);
         const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
         const int threads_per_driver =
@@ -1068,7 +1088,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         {
             std::vector<uint32_t> live, keep;
             std::vector<size_t> bounds;
-            size_t s0 = 0, ns = 0; // first staging slot, nodes in flight
+            size_t s0 = 0, ns = 0; // first query, nodes in flight
+            size_t base = 0;       // first node slot of the group in the staging blocks
             std::atomic<uint32_t> claim{0}; // nodes of the launch being assembled that the workers have claimed
             double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0, t_sub = 0, t_turn = 0, t_idle = 0, t_done = 0;
             int64_t launches = 0, rounds = 0, timed_launches = 0;
@@ -1078,6 +1099,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         for (int gi = 0; gi < ng; ++gi)
         {
             G[gi].s0 = (size_t)gi * gcap;
+            G[gi].base = (size_t)gi * gslots;
             for (size_t i = G[gi].s0; i < std::min(cn, G[gi].s0 + gcap); ++i)
                 G[gi].live.push_back((uint32_t)i);
         }
@@ -1094,7 +1116,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // where a group's results of the current round lie in the staging block (laid out for its current size)
         auto slice = [&](const Group &g, size_t lvl, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
-            size_t o = o_succ + ((&g - G) * DEPTH + lvl) * res_stride(gcap * KS);
+            size_t o = o_succ + ((&g - G) * DEPTH + lvl) * res_stride(gslots);
             p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
             p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
             p_ok = o, o += (g.ns + 15) & ~(size_t)15;
@@ -1124,6 +1146,19 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             for (int w = 0; w <= nw; ++w)
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             g.claim.store(0, std::memory_order_relaxed);
+            // this round's widths: the call's, or what the queries still alive leave room for (every group takes the
+            // call to be as thinned out as itself)
+            int r_spec_k = spec_k, r_tree = tree_cfg, r_ahead = ahead_cfg;
+            bool r_adapt = spec_adapt;
+            if (widths_follow_live)
+            {
+                const int share = share_of(g.live.size() * (size_t)ng);
+                const bool fixed = share >= SHARE_FIXED;
+                r_adapt = !fixed;
+                r_spec_k = fixed ? std::min(16, 4 + (share + 2) / 5) : 6;
+                r_tree = fixed && m.ad_mode == 0 ? share - r_spec_k : 0;
+                r_ahead = m.ad_mode == 0 ? 1 : 0;
+            }
             gp.run_parts([&](int w) {
                 uint64_t hits = 0, deep = 0, ahead = 0, n_ahead_sent = 0, n_open_sent = 0, c_consume = 0, c_advance = 0, c_next = 0;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
@@ -1230,8 +1265,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                                 ++deep;
                         }
                         // width of the next round: two beyond the deepest entry that was used, one less when none was
-                        if (spec_adapt)
-                            q.spec_w = deepest ? std::min(spec_k - 1, deepest + 2) : std::max(spec_floor, q.spec_w - 1);
+                        if (r_adapt)
+                            q.spec_w = deepest ? std::min(r_spec_k - 1, deepest + 2) : std::max(spec_floor, q.spec_w - 1);
                     }
                     else
                         want = !q.done && D.advance(q);
@@ -1240,7 +1275,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     if (want)
                     {
                         q.spec[0] = q.cur;
-                        const int extra = spec_adapt ? std::min(q.spec_w, spec_k - 1) : spec_k - 1;
+                        const int extra = r_adapt ? std::min(q.spec_w, r_spec_k - 1) : r_spec_k - 1;
                         q.nspec = 1 + (extra > 0 ? D.next_best(q, q.spec + 1, extra) : 0);
                         q.n_open = q.nspec;
                         for (int i = 0; i < q.nspec; ++i)
@@ -1253,13 +1288,13 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                         }
                         // nodes that do not exist yet: for the popped node (and, HYAS_AHEAD_WIDTH > 1, the open-list
                         // entries behind it) the successor by the node's own motion-set entry, that one's successor ...
-                        if (tree_cfg)
+                        if (r_tree)
                         {
                             // breadth first from the popped node; a parent's own motion-set entry comes first
                             int8_t queue[HYAS_MAX_NODES];
                             int head = 0, tail = 0;
                             queue[tail++] = 0;
-                            const int limit = q.n_open + tree_cfg;
+                            const int limit = q.n_open + r_tree;
                             while (head < tail && q.nspec < limit)
                             {
                                 const int parent = queue[head++];
@@ -1290,7 +1325,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             StepIn from = stage[qi * KS + root];
                             int parent = root, made_by = q.arena[q.spec[root]].cand;
                             const int kind = root ? 1 : 0; // the figures of the popped node and of the others differ
-                            for (int a = 0; a < ahead_cfg && made_by >= 0 && made_by < 8 && made_by < m.n_succ; ++a)
+                            for (int a = 0; a < r_ahead && made_by >= 0 && made_by < 8 && made_by < m.n_succ; ++a)
                             {
                                 // the entry this search has followed most often after a node made by `made_by`; the
                                 // same entry again until there is something to go by
@@ -1351,7 +1386,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                         continue;
                     slot0[qi] = at;
                     for (int i = 0; i < Q[qi].nspec; ++i)
-                        r_in[g.s0 * KS + at++] = stage[qi * KS + i];
+                        r_in[g.base + at++] = stage[qi * KS + i];
                 }
                 if (c->d_nodes && mine)
                     __builtin_ia32_sfence(); // stores into device memory leave this core's write-combining buffers
@@ -1378,7 +1413,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         auto launch = [&](Group &g, int gi) -> int {
             hipStream_t st = c->round_stream[gi];
             hipEvent_t *ev = c->round_ev[gi];
-            const size_t s0 = g.s0, ns = g.ns;
+            const size_t s0 = g.base, ns = g.ns;
             const double t0 = now();
             g.t_sub = t0;
             if (g.t_done > 0)
@@ -1393,8 +1428,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             {
                 size_t p_succ, p_len, p_ok, p_cnt;
                 slice(g, l, p_succ, p_len, p_ok, p_cnt);
-                const StepIn *d_in = l == 0 ? k_in + s0 * KS : (const StepIn *)(ds + o_child + (l - 1) * child_stride) + s0 * KS;
-                StepIn *d_child = l + 1 < DEPTH ? (StepIn *)(ds + o_child + l * child_stride) + s0 * KS : nullptr;
+                const StepIn *d_in = l == 0 ? k_in + s0 : (const StepIn *)(ds + o_child + (l - 1) * child_stride) + s0;
+                StepIn *d_child = l + 1 < DEPTH ? (StepIn *)(ds + o_child + l * child_stride) + s0 : nullptr;
                 launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
                              (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
                              c->stats_mode, st, d_child, P_analytic);

@@ -162,11 +162,12 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
                 dict(HYAS_DEPTH="1"), dict(HYAS_DEPTH="2"), dict(HYAS_DEPTH="3", HYAS_SPEC="3"), dict(HYAS_DEPTH="4", HYAS_SPEC="1", HYAS_GROUPS="2"),
                 dict(HYAS_DEPTH="2", HYAS_CHUNK="97", HYAS_NODES_IN_HOST_MEMORY="1"),
                 dict(HYAS_AHEAD="0"), dict(HYAS_AHEAD="1", HYAS_SPEC="1"), dict(HYAS_AHEAD="4", HYAS_SPEC="8"), dict(HYAS_AHEAD="3", HYAS_DEPTH="2"),
-                dict(HYAS_AHEAD="1", HYAS_AHEAD_WIDTH="4"), dict(HYAS_PIN="0"),
+                dict(HYAS_AHEAD="1", HYAS_AHEAD_WIDTH="4"), dict(HYAS_PIN="0"), dict(HYAS_LIVE_WIDTHS="0"),
+                dict(HYAS_GROUPS="1"), dict(HYAS_GROUPS="7", HYAS_CHUNK="61"),
                 dict(HYAS_TREE="42", HYAS_SPEC="10", HYAS_SPEC_ADAPT="0"), dict(HYAS_TREE="7", HYAS_DEPTH="2"), dict(HYAS_TREE="48", HYAS_SPEC="1"), dict(HYAS_AHEAD="2", HYAS_AHEAD_WIDTH="2", HYAS_SPEC="8"),
                 dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"), dict()):
         for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS",
-                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH", "HYAS_PIN", "HYAS_TREE"):
+                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH", "HYAS_PIN", "HYAS_TREE", "HYAS_LIVE_WIDTHS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
