@@ -28,7 +28,6 @@ namespace
 #define HYAS_MAX_SPEC 24   // most open-list entries of one query in one launch
 #define HYAS_MAX_TREE 100  // most nodes of one query in one launch that do not exist yet
 #define HYAS_MAX_NODES 124 // most nodes of one query in one launch
-static size_t ROUND_NODES = 2048; // nodes per round over all queries of a call that the widths aim at
 constexpr int SHARE_MIN = 7, SHARE_MAX = 64, SHARE_FIXED = 11; // a query's share of them: least, most, fixed widths from here up
 #define HYAS_MAX_DEPTH 4 // most launches per round: each expands the lowest-f successors of the one before
 
@@ -790,21 +789,23 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // A query sends fewer extra nodes while its speculation is not paying off: two beyond the deepest entry the
     // search used last round, one less (down to HYAS_SPEC_FLOOR) after a round that used none.  HYAS_SPEC_ADAPT=0
     // sends the full width every round.
-    // The fewer queries a call brings (the plugin's makePlan: one), the more room a launch has for nodes of each: about
-    // 5600 nodes per round over all queries is what the GPU takes before the rounds get longer faster than they get
-    // fewer (measured on maze batches of 1 to 1024 queries).  Per query: at most 64 nodes -- 16 open-list entries and
-    // the popped node's neighbourhood (HYAS_TREE below), 27.0 instead of 46.9 ms for one maze query per call -- down
-    // to the 6 + 1 of large batches; below 11 per query the width follows each query's recent use, above it is fixed.
-    // The share is worked out again every round from the queries still alive (a batch thins out as its searches end:
-    // the benchmark batch spends most of its rounds with a quarter of its queries), unless one of HYAS_SPEC,
-    // HYAS_SPEC_ADAPT, HYAS_AHEAD, HYAS_AHEAD_WIDTH, HYAS_TREE fixes the widths for the whole call.
-    auto share_of = [](size_t queries) { return (int)std::min<size_t>(SHARE_MAX, std::max<size_t>(SHARE_MIN, ROUND_NODES / std::max<size_t>(queries, 1))); };
-    if (const char *e = std::getenv("HYAS_ROUND_NODES"))
-        ROUND_NODES = (size_t)std::max(64, std::atoi(e));
+    // The fewer queries are alive (the plugin's makePlan brings one), the more room a launch has for nodes of each:
+    // about 2000 nodes per round over all live queries is what the GPU takes before the rounds get longer faster than
+    // they get fewer (measured on maze batches of 1 to 1024 queries).  Per query: at most 64 nodes -- 16 open-list
+    // entries and the popped node's neighbourhood (HYAS_TREE below), 27 instead of 47 ms for one maze query per call --
+    // down to the 6 + 1 of large batches; below 11 per query the width follows each query's recent use, above it is
+    // fixed.  The share is worked out every round from the queries still alive (a batch thins out as its searches
+    // end: the benchmark batch spends most of its rounds with a quarter of its queries), unless one of HYAS_SPEC,
+    // HYAS_SPEC_ADAPT, HYAS_AHEAD, HYAS_AHEAD_WIDTH, HYAS_TREE fixes the widths for the whole call; widths worked out
+    // once from the size of the call (HYAS_LIVE_WIDTHS=0) take 5632 nodes per round, which allows for the thinning.
+    const size_t ROUND_NODES = std::getenv("HYAS_ROUND_NODES") ? (size_t)std::max(64, std::atoi(std::getenv("HYAS_ROUND_NODES"))) : 2048;
+    auto share_of = [](size_t queries, size_t nodes) {
+        return (int)std::min<size_t>(SHARE_MAX, std::max<size_t>(SHARE_MIN, nodes / std::max<size_t>(queries, 1)));
+    };
     const bool widths_follow_live = !(std::getenv("HYAS_SPEC") || std::getenv("HYAS_SPEC_ADAPT") || std::getenv("HYAS_AHEAD") ||
                                       std::getenv("HYAS_AHEAD_WIDTH") || std::getenv("HYAS_TREE") ||
                                       (std::getenv("HYAS_LIVE_WIDTHS") && std::atoi(std::getenv("HYAS_LIVE_WIDTHS")) == 0));
-    const int per_query = share_of(n);
+    const int per_query = share_of(n, 5632);
     const bool few_queries = per_query >= SHARE_FIXED;
     const bool spec_adapt = std::getenv("HYAS_SPEC_ADAPT") ? std::atoi(std::getenv("HYAS_SPEC_ADAPT")) != 0 : !few_queries;
     const int spec_floor = std::getenv("HYAS_SPEC_FLOOR") ? std::max(0, std::atoi(std::getenv("HYAS_SPEC_FLOOR"))) : 2;
@@ -1152,7 +1153,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             bool r_adapt = spec_adapt;
             if (widths_follow_live)
             {
-                const int share = share_of(g.live.size() * (size_t)ng);
+                const int share = share_of(g.live.size() * (size_t)ng, ROUND_NODES);
                 const bool fixed = share >= SHARE_FIXED;
                 r_adapt = !fixed;
                 r_spec_k = fixed ? std::min(16, 4 + (share + 2) / 5) : 6;
