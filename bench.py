@@ -121,7 +121,7 @@ def parse_args(argv=None):
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step (queries_large: in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="queries_maze",
-                    choices=["queries_maze", "queries_large", "footprint_checks", "footprint_checks_car", "rs_table", "single_query"],
+                    choices=["queries_maze", "queries_large", "footprint_checks", "footprint_checks_car", "rs_table", "single_query", "modes"],
                     help="queries_maze is the benchmark the metric is quoted on; the others are the remaining configurations")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="weak: every GPU gets --queries queries; strong: the batch is split into contiguous blocks "

@@ -5,7 +5,10 @@
  rs_table          Reeds-Shepp heuristic table of a 180 x 60 map (rho 0.35), heading slices sharded over the
                    GPUs and assembled with one all-gather, then installed on every GPU;
  queries_large     65 536 planning queries on maps/map_large sharded over the GPUs (strong scaling);
- single_query      the maze queries one per call, as the reference's makePlan hands them over: latency per query.
+ single_query      the maze queries one per call, as the reference's makePlan hands them over: latency per query;
+ modes             the maze batch under the reference's other configurations: adaptive steering angle and step size,
+                   adaptive step size, cubic Bezier curves, the shipped parameter file (obstacle range 6 m), and the
+                   path shortcut on its own (hyas_shortcut_batch), each with the map set-up time.
 
 Same output contract as bench.py: one JSON line on rank 0.
 """
@@ -311,8 +314,112 @@ def single_query(args):
     }
 
 
+def modes(args):
+    """The 1024-query maze batch under the configurations beside the benchmark's (one GPU): per configuration the map
+    set-up time (obstacle lists, adaptive maps, heuristic table), the batch time and rates, and the CPU oracle on a
+    bounded sample of the same queries; then hyas_shortcut_batch on the paths the batch found."""
+    torch, dist, rank, local_rank, world = _dist_setup()
+    from path_planner_amd import Hyas, hot_path_params
+    from path_planner_amd import _lib as hl
+    from path_planner_amd.sharding import load_map, make_queries
+
+    mp = load_map("map_maze")
+    H, W = mp.shape
+    base = Hyas(hot_path_params(), device=local_rank)
+    base.set_costmap(mp, build_table=True)
+    nq = args.queries
+    starts, goals = make_queries(base.collision, nq, 20250228, W, H)
+    shipped = {k: v for k, v in hl.SHIPPED_YAML.items()}
+    shipped.update(obstacle_detection_range=6.0, max_iterations=10000)
+    variants = {
+        "benchmark (Reeds-Shepp, fixed motion set)": {},
+        "adaptive steering angle and step size": dict(adaptive_steering_angle_and_step_size=1),
+        "adaptive step size": dict(adaptive_step_size=1),
+        "cubic Bezier curves": dict(curve_type=2),
+        "Dubins curves, shots at the paper's schedule": dict(curve_type=0, analytical_expansion_every_point=0),
+        "shipped parameter file with a 6 m obstacle range": shipped,
+    }
+    rows = {}
+    cpu_on = world == 1 and not args.no_cpu_baseline
+    if cpu_on:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import orc
+    keep_paths = None
+    for name, kw in variants.items():
+        make = hl.default_params if kw is shipped else hot_path_params
+        ctx = Hyas(make(**kw), device=local_rank)
+        t0 = time.perf_counter()
+        ctx.set_costmap(mp, build_table=True)
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        ctx.plan_batch(starts[:64], goals[:64])
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = ctx.plan_batch(starts, goals)
+        sec = (time.perf_counter() - t0) / args.steps
+        kms, kl = ctx.kernel_ms(0)
+        status = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
+        row = {"map_setup_ms": setup_ms, "ms_per_batch": sec * 1e3, "queries_per_s": nq / sec,
+               "successors_per_s": float(res["successors"].sum()) / sec, "nodes_expanded_per_s": float(res["nodes_expanded"].sum()) / sec,
+               "round_kernel_avg_us": 1e3 * kms / max(kl, 1), "rounds_per_group": kl, "status_counts": status}
+        if name.startswith("benchmark"):
+            keep_paths = [ctx.path(i) for i in range(nq) if res["status"][i] in (hl.STATUS_SHOT, 1) and res["path_len"][i] >= 3]
+        if cpu_on:
+            make_o = orc.default_params if kw is shipped else orc.hot_path_params
+            o = orc.Oracle(make_o(**kw))
+            t0 = time.perf_counter()
+            o.set_costmap(mp, build_table=True, nthreads=1)
+            o_setup = time.perf_counter() - t0
+            order = np.random.default_rng(1).permutation(nq)
+            t0 = time.perf_counter()
+            done = succ = 0
+            for i in order:
+                r, _, _ = o.plan(starts[i], goals[i])
+                done += 1
+                succ += int(r["successors"])
+                if time.perf_counter() - t0 > 4.0:
+                    break
+            cs = time.perf_counter() - t0
+            row["cpu_oracle"] = {"map_setup_ms": o_setup * 1e3, "queries_per_s": done / cs, "successors_per_s": succ / cs, "cores": 1,
+                                 "sample": f"{done} of the {nq} queries (seeded shuffle) in {cs:.1f} s on one thread"}
+        rows[name] = row
+        ctx.close()
+    # ShortCut on its own: the paths of the benchmark configuration (short_cut is off there)
+    sc = None
+    if keep_paths:
+        base.shortcut(keep_paths[:8])
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            kept = base.shortcut(keep_paths)
+        sec = (time.perf_counter() - t0) / args.steps
+        poses = int(sum(len(p) for p in keep_paths))
+        sc = {"paths": len(keep_paths), "poses": poses, "ms_per_call": sec * 1e3, "paths_per_s": len(keep_paths) / sec,
+              "poses_per_s": poses / sec, "poses_kept": int(sum(len(k) for k in kept))}
+        if cpu_on:
+            o = orc.Oracle(orc.hot_path_params())
+            o.set_costmap(mp, build_table=False)
+            t0 = time.perf_counter()
+            done = 0
+            for p_ in keep_paths:
+                o.shortcut(p_)
+                done += 1
+                if time.perf_counter() - t0 > 4.0:
+                    break
+            cs = time.perf_counter() - t0
+            sc["cpu_oracle"] = {"paths_per_s": done / cs, "cores": 1, "sample": f"{done} paths in {cs:.1f} s on one thread"}
+    if rank != 0:
+        return None
+    head = rows["shipped parameter file with a 6 m obstacle range"]
+    return {
+        "metric": "collision-checked node expansions/sec", "value": head["successors_per_s"], "unit": "successors/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_batch"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"map_maze 50x50, {nq} queries, one GPU; `value` is the shipped-parameter-file row"},
+        "rows": rows, "shortcut": sc, "roofline": None, "cpu_baseline": head.get("cpu_oracle"),
+    }
+
+
 def run(args):
-    fn = {"single_query": single_query, "footprint_checks": footprint_checks, "footprint_checks_car": lambda a: footprint_checks(a, "car"), "rs_table": rs_table,
+    fn = {"single_query": single_query, "modes": modes, "footprint_checks": footprint_checks, "footprint_checks_car": lambda a: footprint_checks(a, "car"), "rs_table": rs_table,
           "queries_large": queries_large}[args.workload]
     line = fn(args)
     if line is not None:

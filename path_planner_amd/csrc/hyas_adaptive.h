@@ -292,13 +292,121 @@ HD void select_pairs(const DevMap &m, const Cell &c, float x, float y, float t, 
         }
     }
 }
+// ---- the same selection, laid out for a group of lanes ---------------------------------------------------------------
+// select_pairs() walks the node's ranges once per candidate and normalises every range's ends on every visit: one long
+// dependent chain.  The pieces below let the lanes of a node work side by side: range_pre() once per range; emit_range()
+// forms the candidates of ONE range (they depend on the node and the ranges only, not on what has been emitted so far);
+// merge_emitted() then applies the reference's duplicate rule to them in range order, which is all that has to be
+// serial.  Same functions on the same values as select_pairs(): the lists are identical, bit for bit.  Not for
+// fixed_number_of_steering_angle_in_free_angle_range = 0 (a free range then emits a fan of any length).
+struct RangePre // a range's ends in both normal forms
+{
+    float s0, e0, sn, en;
+};
+HD RangePre range_pre(const Range &r)
+{
+    const float end = range_end(r.start, r.range);
+    RangePre p;
+    p.s0 = rad_0_2pi(r.start), p.e0 = rad_0_2pi(end), p.sn = rad_norm(r.start), p.en = rad_norm(end);
+    return p;
+}
+// range_includes(r.start, r.range, angle) with a2 = rad_0_2pi(angle), an = rad_norm(angle) formed by the caller
+HD bool range_includes_pre(const Range &r, const RangePre &p, float angle, float a2, float an)
+{
+    if (angle_equal(angle, r.start) || angle_equal(angle, range_end(r.start, r.range)))
+        return true;
+    if (a2 >= p.s0 && a2 <= p.e0)
+        return true;
+    return an >= p.sn && an <= p.en;
+}
+HD float find_step_size_pre(const DevMap &m, const Cell &c, const RangePre *pre, float t, float steering, float dist_to_goal, float fixed_step)
+{
+    float min_dist = m.ad_range;
+    const float final_orientation = rad_norm(t + steering);
+    const float a2 = rad_0_2pi(final_orientation), an = rad_norm(final_orientation);
+    for (uint32_t i = 0; i < c.n; ++i)
+        if (range_includes_pre(c.rng[i], pre[i], final_orientation, a2, an))
+        {
+            min_dist = c.rng[i].dist;
+            break;
+        }
+    const float weight = (float)(-0.8 * (double)c.density + 0.9);
+    float step = weight * min_dist;
+    if (step < fixed_step)
+        step = fixed_step;
+    if (step > dist_to_goal)
+        step = dist_to_goal;
+    return step;
+}
+#define HYAS_AD_EMIT_MAX 3 // candidates of one range at most: the extra successor towards the goal and two steering angles
+// the steering angle of the extra successor (SelectStepSizeAndSteeringAngle, :736-749)
+HD float toward_goal_steering(const DevMap &m, float x, float y, float t, float gx, float gy, float gt, float dist_start_goal)
+{
+    if (!m.ad_one_more)
+        return 0;
+    const float dist_to_goal = normf(sub(f2(x, y), f2(gx, gy)));
+    const float weighting = dist_to_goal / dist_start_goal;
+    const float angle_to_goal = rad_0_2pi(hy_atan2f(gy - y, gx - x));
+    const float orientation_diff = -rad_norm(t - gt);
+    return -rad_norm(weighting * angle_to_goal + (1 - weighting) * orientation_diff);
+}
+// candidates {step, steering angle} of range i in the order select_pairs() pushes them; returns how many
+HD int emit_range(const DevMap &m, const Cell &c, const RangePre *pre, uint32_t i, float t, float dist_to_goal, float toward_goal, float fixed_step,
+                  float *step, float *steer)
+{
+    const float lim = deg2rad(30);
+    int n = 0;
+    const auto one_more = [&]() {
+        const float st = find_step_size_pre(m, c, pre, t, toward_goal, dist_to_goal, fixed_step);
+        step[n] = dist_to_goal < st ? dist_to_goal : st, steer[n] = limit_steering(toward_goal, lim), ++n;
+    };
+    const auto steer_to = [&](float steering) {
+        step[n] = find_step_size_pre(m, c, pre, t, steering, dist_to_goal, fixed_step), steer[n] = steering, ++n;
+    };
+    const float dist = c.rng[i].dist, start = c.rng[i].start, range = c.rng[i].range;
+    if (range == 0)
+    {
+        step[n] = dist, steer[n] = limit_steering(rad_norm(start - t), lim), ++n;
+        return n;
+    }
+    if (dist == m.ad_range)
+    {
+        if (m.ad_one_more)
+            one_more();
+        steer_to(limit_steering(rad_norm((float)((double)start + 0.5 * (double)range - (double)t)), lim));
+    }
+    else
+    {
+        if (m.ad_one_more && !m.ad_one_more_free_only)
+            one_more();
+        if (m.ad_towards_free)
+            steer_to(limit_steering(rad_norm(closest_to_free_range(m, c, start, range_end(start, range)) - t), lim));
+        else
+        {
+            steer_to(limit_steering(rad_norm(start - t), lim));
+            steer_to(rad_norm(start + range - t));
+        }
+    }
+    return n;
+}
+// can the staged form be used for this configuration?  (a narrow free range takes the middle either way; a wide one fans out)
+HD bool staged_selection_applies(const DevMap &m) { return m.ad_fixed_number != 0; }
+// counts[i] candidates of range i at step/steer[i * HYAS_AD_EMIT_MAX ...]: the reference's list
+HD void merge_emitted(const Cell &c, const int *counts, const float *step, const float *steer, Pairs &out)
+{
+    out.n = 0, out.overflow = false;
+    for (uint32_t i = 0; i < c.n; ++i)
+        for (int j = 0; j < counts[i]; ++j)
+            push_pair(out, step[i * HYAS_AD_EMIT_MAX + j], steer[i * HYAS_AD_EMIT_MAX + j]);
+}
+
 // The pair list of CreateSuccessor(pred) without the reverse pair (src/hybrid_a_star.cpp:547-621).
 // m.ad_mode: 1 adaptive_steering_angle_and_step_size, 2 adaptive_step_size.
-HD void step_steer_pairs(const DevMap &m, float x, float y, float t, float gx, float gy, float gt, float dist_start_goal, Pairs &out)
+// c: the cell of (x, y) as cell_of gives it, or a copy of it with the ranges somewhere faster
+HD void step_steer_pairs(const DevMap &m, const Cell &c, float x, float y, float t, float gx, float gy, float gt, float dist_start_goal, Pairs &out)
 {
     out.n = 0, out.overflow = false;
     const float dist_to_goal = normf(sub(f2(x, y), f2(gx, gy)));
-    const Cell c = cell_of(m, x, y);
     if (m.ad_mode == 1)
     {
         if (c.density > m.ad_constant_density)
@@ -317,6 +425,11 @@ HD void step_steer_pairs(const DevMap &m, float x, float y, float t, float gx, f
             if (!m.succ_reverse[k])
                 out.step[out.n] = find_step_size(m, c, t, m.succ_steer[k], dist_to_goal, m.res_f), out.steer[out.n] = m.succ_steer[k], ++out.n;
     }
+}
+
+HD void step_steer_pairs(const DevMap &m, float x, float y, float t, float gx, float gy, float gt, float dist_start_goal, Pairs &out)
+{
+    step_steer_pairs(m, cell_of(m, x, y), x, y, t, gx, gy, gt, dist_start_goal, out);
 }
 
 // ---- per costmap (host) ------------------------------------------------------------------------------------------

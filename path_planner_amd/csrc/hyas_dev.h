@@ -589,6 +589,12 @@ HD bool seg_ray_hits_quad(F2 s, F2 e, const Quad &q)
     }
     return false;
 }
+// LONG: the segment may be metres long (adaptive step sizes, ShortCut), so that its box holds many quads it passes at
+// a distance: a quad whose four vertices lie on one side of the segment's line, farther than r from it, has no edge
+// that crosses the segment, no edge within r of a segment end (the ends are on the line) and no vertex within r of the
+// segment: none of the candidates above can fire (r = half_wid + cull_margin covers the reference's rounding and snaps
+// as for the box tests; the products below are exact to a few 1e-5 m at map scale).
+template <bool LONG = false>
 HD bool seg_hits_quad(float r, double half_wid, F2 s, F2 e, const Quad &q)
 {
     if (seg_ray_hits_quad(s, e, q))
@@ -597,6 +603,21 @@ HD bool seg_hits_quad(float r, double half_wid, F2 s, F2 e, const Quad &q)
     const float symin = fminf_(s.y, e.y) - r, symax = fmaxf_(s.y, e.y) + r;
     if (q.xmax < sxmin || sxmax < q.xmin || q.ymax < symin || symax < q.ymin)
         return false;
+    if (LONG)
+    {
+        const float nx = s.y - e.y, ny = e.x - s.x; // normal of the line, as long as the segment
+        const float far = r * hy_sqrtf(nx * nx + ny * ny) * 1.0001f;
+        float lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const F2 v = qv(q, i);
+            const float d = nx * (v.x - s.x) + ny * (v.y - s.y);
+            lo = i ? fminf_(lo, d) : d, hi = i ? fmaxf_(hi, d) : d;
+        }
+        if (lo > far || hi < -far)
+            return false;
+    }
     return seg_hits_verts_near(r, half_wid, s, e, qv(q, 0), qv(q, 1), qv(q, 2), qv(q, 3));
 }
 
@@ -617,6 +638,11 @@ HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, 
     const bool walk0 = ks < cells, walk1 = ke < cells && ke != ks;
     const uint32_t b0 = walk0 ? off[ks] : 0u, e0 = walk0 ? off[ks + 1] : 0u;
     const uint32_t b1 = walk1 ? off[ke] : 0u, e1 = walk1 ? off[ke + 1] : 0u;
+    // A long segment reads the full lists of two cells that lie metres apart at most: mostly the same quads.  The
+    // verdict is an OR over quads, so the second walk passes over the ones the first has tested (quad numbers below
+    // 192, the ones kept in workgroup memory, are remembered in three words).
+    uint64_t seen0 = 0, seen1 = 0, seen2 = 0;
+    const bool remember = !pruned && walk0 && walk1;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass)
     {
@@ -630,9 +656,19 @@ HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, 
             if (quads.stop())
                 return true; // the caller no longer needs this verdict
             const uint16_t ent = cur.at(k);
+            if (remember && (ent & 0x7fffu) < 192u)
+            {
+                const uint32_t id = ent & 0x7fffu;
+                const uint64_t bit = 1ull << (id & 63u);
+                uint64_t &word = id < 64u ? seen0 : (id < 128u ? seen1 : seen2);
+                if (pass && (word & bit))
+                    continue;
+                word |= bit;
+            }
             const Quad q = quads(ent & 0x7fffu);
             // bit 15 (pruned lists only): only the ray-casting test can fire
-            if ((pruned && (ent & 0x8000u)) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad(r, m.half_wid, s, e, q))
+            if (pruned ? ((ent & 0x8000u) ? seg_ray_hits_quad(s, e, q) : seg_hits_quad<false>(r, m.half_wid, s, e, q))
+                       : seg_hits_quad<true>(r, m.half_wid, s, e, q))
             {
                 quads.hit();
                 return false;

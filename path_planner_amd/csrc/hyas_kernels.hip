@@ -869,12 +869,60 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     const float *my_twod = twod ? twod + (size_t)node.query * m.twod_size : nullptr;
     const bool pose_lane = tid < EXPAND_THREADS / 2, seg_lane = !pose_lane;
     const float dist = normf(sub(f2(node.x, node.y), f2(goal.x, goal.y)));
-    if (ADAPT == 1 && live && pose_lane && sl == 0)
+    // Adaptive modes: the angle ranges of the node's cell are walked once per candidate, every step depending on the
+    // one before: from global memory that is a chain of some eighty cache round trips.  The node's lanes fetch the
+    // ranges side by side into workgroup memory first (cells with more than AD_LDS_RANGES keep to global memory).
+    constexpr int AD_LDS_RANGES = 16;
+    __shared__ ad::Range s_rng[ADAPT != 0 ? NODES : 1][AD_LDS_RANGES];
+    ad::Cell cell;
+    cell.rng = nullptr, cell.n = 0, cell.density = 0;
+    if (ADAPT != 0 && live)
     {
-        ad::Pairs p;
-        p.step = s_step[local], p.steer = s_steer[local];
-        ad::step_steer_pairs(m, node.x, node.y, node.t, goal.x, goal.y, goal.t, __uint_as_float(node.pad), p);
-        s_pairs[local] = p.overflow ? -1 : p.n;
+        cell = ad::cell_of(m, node.x, node.y);
+        if (pose_lane && cell.n <= (uint32_t)AD_LDS_RANGES)
+            for (uint32_t i = (uint32_t)sl; i < cell.n; i += LANES)
+                s_rng[local][i] = cell.rng[i];
+    }
+    if (ADAPT != 0)
+    {
+        __syncthreads();
+        if (live && cell.n <= (uint32_t)AD_LDS_RANGES)
+            cell.rng = s_rng[local];
+    }
+    if constexpr (ADAPT == 1)
+    {
+        // The node's {step, steering} list.  Formed by one lane alone it is the longest chain of the launch (every
+        // candidate walks all ranges, normalising their ends on the way), so the node's lanes share it out: lane i
+        // takes range i -- its ends in normal form, then its candidates -- and the first lane only applies the
+        // duplicate rule to what the others found, in range order.  (Not for the configurations and cells named
+        // at ad::emit_range: the first lane then forms the list by itself.)
+        static_assert(LANES >= AD_LDS_RANGES, "one lane per staged range");
+        __shared__ ad::RangePre s_pre[NODES][AD_LDS_RANGES];
+        __shared__ float s_estep[NODES][AD_LDS_RANGES * HYAS_AD_EMIT_MAX], s_esteer[NODES][AD_LDS_RANGES * HYAS_AD_EMIT_MAX];
+        __shared__ int s_ecount[NODES][AD_LDS_RANGES];
+        const bool shared_out = live && ad::staged_selection_applies(m) && cell.n <= (uint32_t)AD_LDS_RANGES &&
+                                !(cell.density > m.ad_constant_density);
+        const bool my_range = shared_out && pose_lane && (uint32_t)sl < cell.n;
+        if (my_range)
+            s_pre[local][sl] = ad::range_pre(cell.rng[sl]);
+        __syncthreads();
+        if (my_range)
+        {
+            const float toward = ad::toward_goal_steering(m, node.x, node.y, node.t, goal.x, goal.y, goal.t, __uint_as_float(node.pad));
+            s_ecount[local][sl] = ad::emit_range(m, cell, s_pre[local], (uint32_t)sl, node.t, dist, toward, m.res_f,
+                                                 &s_estep[local][sl * HYAS_AD_EMIT_MAX], &s_esteer[local][sl * HYAS_AD_EMIT_MAX]);
+        }
+        __syncthreads();
+        if (live && pose_lane && sl == 0)
+        {
+            ad::Pairs p;
+            p.step = s_step[local], p.steer = s_steer[local];
+            if (shared_out)
+                ad::merge_emitted(cell, s_ecount[local], s_estep[local], s_esteer[local], p);
+            else
+                ad::step_steer_pairs(m, cell, node.x, node.y, node.t, goal.x, goal.y, goal.t, __uint_as_float(node.pad), p);
+            s_pairs[local] = p.overflow ? -1 : p.n;
+        }
     }
     __syncthreads(); // quads staged, pair lists formed
     bool part_ok = false, evaluated = false, overflow = false;
@@ -900,7 +948,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
             have = true, steer = m.succ_steer[sl];
             const bool rev = m.succ_reverse[sl] != 0;
             if (ADAPT == 2 && !rev) // src/hybrid_a_star.cpp:585-599
-                first = ad::find_step_size(m, ad::cell_of(m, node.x, node.y), node.t, steer, dist, m.res_f);
+                first = ad::find_step_size(m, cell, node.t, steer, dist, m.res_f);
             else
                 first = motion_step(rev, dist);
         }

@@ -18,6 +18,7 @@ timeout -k 10 300 python3 -u bench.py --workload footprint_checks_car > "$out/ex
 timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 1 > "$out/extra_table_pr1.json" 2> "$out/extra_table_pr1.err"
 timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 10 > "$out/extra_table_pr10.json" 2> "$out/extra_table_pr10.err"
 timeout -k 10 300 python3 -u bench.py --workload single_query --steps 1 > "$out/extra_single_query.json" 2> "$out/extra_single_query.err"
+timeout -k 10 600 python3 -u bench.py --workload modes --steps 2 > "$out/extra_modes.json" 2> "$out/extra_modes.err"
 echo "extras done"
 HYAS_TRACE=1 timeout -k 10 600 python3 -u bench.py --workload queries_large --steps 1 --warmup 0 > "$out/extra_queries_large.json" 2> "$out/extra_queries_large.err"
 echo "large done"

@@ -347,8 +347,10 @@ extern "C" int hg_ranges_of_sweep(const float *angle, const float *dist, int n, 
 // steering set.  pairs2: n x 13 x {step, steer}; counts[i] = pairs of node i, -1 on overflow.
 extern "C" void hg_step_steer_pairs(int w, int h, double res, double ox, double oy, const uint32_t *ad_off, const float *ad_rng, const float *ad_density,
                                     float detection_range, float constant_density, int mode, int flags, const float *steer, int n_steer,
-                                    const float *nodes_xyt, const float *goals_xyt, const float *dist_start_goal, int n, float *pairs2, int *counts)
+                                    const float *nodes_xyt, const float *goals_xyt, const float *dist_start_goal, int n, float *pairs2, int *counts,
+                                    int *shared_out_checked)
 {
+    *shared_out_checked = 0;
     DevMap m{};
     m.w = w, m.h = h, m.res = res, m.ox = ox, m.oy = oy, m.res_f = (float)res, m.ox_f = (float)ox, m.oy_f = (float)oy;
     int e = 0;
@@ -370,6 +372,30 @@ extern "C" void hg_step_steer_pairs(int w, int h, double res, double ox, double 
         counts[i] = p.overflow ? -1 : p.n;
         for (int k = 0; k < p.n; ++k)
             pairs2[(i * HYAS_AD_MAX_PAIRS + k) * 2] = st[k], pairs2[(i * HYAS_AD_MAX_PAIRS + k) * 2 + 1] = sa[k];
+        // the form the kernel's lanes share out (range by range, then the duplicate rule) must give the same list
+        const float x = nodes_xyt[3 * i], y = nodes_xyt[3 * i + 1], t = nodes_xyt[3 * i + 2];
+        const ad::Cell c = ad::cell_of(m, x, y);
+        if (mode == 1 && ad::staged_selection_applies(m) && c.n <= 16 && !(c.density > m.ad_constant_density))
+        {
+            ad::RangePre pre[16];
+            float es[16 * HYAS_AD_EMIT_MAX], ea[16 * HYAS_AD_EMIT_MAX];
+            int cnt[16];
+            for (uint32_t r = 0; r < c.n; ++r)
+                pre[r] = ad::range_pre(c.rng[r]);
+            const float gx = goals_xyt[3 * i], gy = goals_xyt[3 * i + 1], gt = goals_xyt[3 * i + 2];
+            const float toward = ad::toward_goal_steering(m, x, y, t, gx, gy, gt, dist_start_goal[i]);
+            const float dist = normf(sub(f2(x, y), f2(gx, gy)));
+            for (uint32_t r = 0; r < c.n; ++r)
+                cnt[r] = ad::emit_range(m, c, pre, r, t, dist, toward, m.res_f, es + r * HYAS_AD_EMIT_MAX, ea + r * HYAS_AD_EMIT_MAX);
+            float st2[HYAS_AD_MAX_PAIRS], sa2[HYAS_AD_MAX_PAIRS];
+            ad::Pairs q;
+            q.step = st2, q.steer = sa2;
+            ad::merge_emitted(c, cnt, es, ea, q);
+            if (q.n != p.n || q.overflow != p.overflow || std::memcmp(st, st2, sizeof(float) * p.n) != 0 || std::memcmp(sa, sa2, sizeof(float) * p.n) != 0)
+                counts[i] = -1000; // no caller expects this value
+            else
+                ++*shared_out_checked;
+        }
     }
 }
 

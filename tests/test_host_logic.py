@@ -248,8 +248,12 @@ def test_adaptive_header_equals_oracle(host_geom, oracle_built):
         steer = np.array([0] + [np.float32(s) * (np.float32(i) * d) for i in range(1, (p.number_of_successors - 1) // 2 + 1) for s in (1, -1)], np.float32)
         pairs = np.zeros((n, 13, 2), np.float32)
         counts = np.zeros(n, np.int32)
+        checked = C.c_int(0)
         host_geom.hg_step_steer_pairs(W, H, C.c_double(1.0), C.c_double(0.0), C.c_double(0.0), vp(off), vp(rr), vp(dens), C.c_float(p.obstacle_detection_range),
-                                      C.c_float(p.constant_density), mode, flags, vp(steer), len(steer), vp(nodes), vp(goals), vp(dsg), n, vp(pairs), vp(counts))
+                                      C.c_float(p.constant_density), mode, flags, vp(steer), len(steer), vp(nodes), vp(goals), vp(dsg), n, vp(pairs), vp(counts),
+                                      C.byref(checked))
+        # the lane-parallel form of the selection was compared with the serial one wherever it applies
+        assert checked.value > n // 2 or mode != 1 or not (flags & 8), (name, mode, flags, checked.value)
         most = 0
         for i in range(n):
             want, nw = o.step_steer_pairs(nodes[i], goals[i], starts[i])
