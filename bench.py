@@ -28,6 +28,9 @@ from pathlib import Path
 
 import numpy as np
 
+# as path_planner_amd does when it loads the library; here because torch is imported first (see _lib.load_library)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 

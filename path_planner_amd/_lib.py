@@ -4,6 +4,7 @@ There is no CPU fallback: if the HIP library is missing or no GPU is usable,
 every compute entry point raises HyasError.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -99,6 +100,10 @@ def load_library():
     if not p.exists():
         raise HyasError(f"{p} is missing: build it with `make -C path_planner_amd/csrc` "
                         "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    # Kernel arguments in device memory: the HIP runtime reads this switch when it starts up (its first call), and it
+    # shortens every launch by 2-3 us, which a search round (one launch per round trip) notices.  A value that is
+    # already set is left alone.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     try:
         # torch bundles its own HIP runtime; if libhyas.so pulled in the system one first, a later
         # `import torch` would bring a second runtime into the process and find no GPU.  Loading torch

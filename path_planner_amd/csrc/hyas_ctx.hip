@@ -660,6 +660,9 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
         return nullptr;
     }
     int ndev = 0;
+    // kernel arguments in device memory (2-3 us less per launch); read by the HIP runtime when it starts up, so this
+    // only takes effect in a process that has made no HIP call yet; a value that is already set is left alone
+    (void)setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
     {
         fprintf(stderr, "hyas_create: no HIP device %d (found %d)\n", device, ndev);
