@@ -165,6 +165,9 @@ int hyas_set_grid(hyas_ctx *ctx, const uint8_t *charmap, uint32_t w, uint32_t h)
  * (:319-354), 0 for an absent key, -1 for a key outside the grid. */
 int hyas_get_obstacles(const hyas_ctx *ctx, float *out, size_t cap_polygons);
 int hyas_in_range_count(const hyas_ctx *ctx, uint32_t key);
+/* The list itself: in_range_obstacle_map_[key] (src/collisiondetection.cpp:335-345) in list order, 8 floats per polygon;
+ * writes at most cap_polygons polygons, returns the list length (-1 for a key outside the grid). */
+int hyas_in_range_list(const hyas_ctx *ctx, uint32_t key, float *out, size_t cap_polygons);
 
 /* replaces: CollisionDetection::IsTraversable(const Node3D&)
  * src/collisiondetection.cpp:93-127 (mode POLYGON) or the footprint-list

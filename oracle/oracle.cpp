@@ -2838,6 +2838,19 @@ int orc_in_range_count(void *h, uint32_t key)
     return it == c->in_range_obstacle_map_.end() ? -1 : (int)it->second.size();
 }
 
+// the list of grid key `key` in list order, 8 floats per obstacle; returns its length, -1 if the key is absent
+int orc_in_range_list(void *h, uint32_t key, float *out, size_t cap)
+{
+    Ctx *c = (Ctx *)h;
+    auto it = c->in_range_obstacle_map_.find(key);
+    if (it == c->in_range_obstacle_map_.end())
+        return -1;
+    for (size_t i = 0; i < it->second.size() && i < cap; ++i)
+        for (int k = 0; k < 4; ++k)
+            out[i * 8 + 2 * k] = it->second[i][k].x, out[i * 8 + 2 * k + 1] = it->second[i][k].y;
+    return (int)it->second.size();
+}
+
 int orc_collision_batch(void *h, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *free_out)
 {
     Ctx *c = (Ctx *)h;

@@ -74,7 +74,7 @@ MODE_POLYGON, MODE_FOOTPRINT = 0, 1
 # every symbol include/hyas.h declares
 EXPORTS = [
     "hyas_default_params", "hyas_hot_path_params", "hyas_create", "hyas_destroy", "hyas_last_error",
-    "hyas_set_costmap", "hyas_set_grid", "hyas_get_obstacles", "hyas_in_range_count", "hyas_collision_batch",
+    "hyas_set_costmap", "hyas_set_grid", "hyas_get_obstacles", "hyas_in_range_count", "hyas_in_range_list", "hyas_collision_batch",
     "hyas_collision_batch_dev", "hyas_footprint_table", "hyas_expand_batch", "hyas_num_successors",
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
@@ -126,6 +126,7 @@ def load_library():
     L.hyas_set_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.hyas_get_obstacles.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.hyas_in_range_count.argtypes = [C.c_void_p, C.c_uint32]
+    L.hyas_in_range_list.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.hyas_collision_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.hyas_collision_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.hyas_footprint_table.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -245,6 +246,12 @@ class Hyas:
 
     def in_range_count(self, key):
         return self.L.hyas_in_range_count(self.h, int(key))
+
+    def in_range_list(self, key):
+        n = max(0, self.L.hyas_in_range_count(self.h, int(key)))
+        out = np.zeros((n, 8), np.float32)
+        self.L.hyas_in_range_list(self.h, int(key), _vp(out), n)
+        return out
 
     def footprint_table(self):
         n = self._check(self.L.hyas_footprint_table(self.h, None, 0), "hyas_footprint_table")

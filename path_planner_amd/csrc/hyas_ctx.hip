@@ -230,20 +230,6 @@ void reset_timers(hyas_ctx *c)
 }
 
 // ------------------------------------------------------------------ ingest
-// nav_msgs::OccupancyGrid value of a costmap cost, src/utility.cpp:185-204
-static int8_t occupancy_of(uint8_t cost)
-{
-    if (cost == 0)
-        return 0;
-    if (cost == 253)
-        return 99;
-    if (cost == 254)
-        return 100;
-    if (cost == 255)
-        return -1;
-    return (int8_t)(1 + (97 * ((int)cost - 1)) / 251);
-}
-
 static Quad make_quad(const float vx[4], const float vy[4])
 {
     Quad q;
@@ -300,8 +286,9 @@ static void cell_axes(const hyas_ctx *c, std::vector<float> &xs, std::vector<flo
         ys.push_back(y);
 }
 
-// CollisionDetection::SetObstacleVec, src/collisiondetection.cpp:262-317
-static void extract_obstacles(hyas_ctx *c, const std::vector<float> &xs, const std::vector<float> &ys)
+// CollisionDetection::SetObstacleVec, src/collisiondetection.cpp:262-317.  occ: the nav_msgs::OccupancyGrid values of
+// the cells (k_occupancy).  Every step of the scan looks at the polygon the step before closed, so it stays a host loop.
+static void extract_obstacles(hyas_ctx *c, const std::vector<int8_t> &occ, const std::vector<float> &xs, const std::vector<float> &ys)
 {
     const float res = (float)c->res;
     DevMap hm = c->dm; // only the scalar members are used by grid_key()
@@ -310,7 +297,7 @@ static void extract_obstacles(hyas_ctx *c, const std::vector<float> &xs, const s
         for (float y : ys)
         {
             uint32_t gi = grid_key(hm, x, y);
-            if (gi >= c->charmap.size() || occupancy_of(c->charmap[gi]) == 0)
+            if (gi >= occ.size() || occ[gi] == 0)
                 continue;
             // CreatePolygon(origin, res, res), src/utility.cpp:457-474
             const float vx[4] = {x, res + x, res + x, x};
@@ -492,14 +479,16 @@ static int upload_footprint_forms(hyas_ctx *c)
 {
     DevMap &m = c->dm;
     const uint32_t w = c->w, h = c->h, tx = (w + 7) / 8, ty = (h + 7) / 8;
-    std::vector<uint64_t> tiles((size_t)tx * ty, 0);
-    for (uint32_t y = 0; y < ty * 8; ++y)
-        for (uint32_t x = 0; x < tx * 8; ++x)
-            if (x >= w || y >= h || c->charmap[(size_t)y * w + x] >= 250)
-                tiles[(size_t)(y >> 3) * tx + (x >> 3)] |= 1ull << (((y & 7) << 3) | (x & 7));
-    int rc = upload(c, c->d_occ_tiles, tiles);
-    if (rc != HYAS_OK)
-        return rc;
+    // occupancy bits packed on the GPU from the uploaded cost bytes: plain tiles and the bordered form
+    const size_t n_tiles = (size_t)tx * ty, n_pad = (size_t)(tx + 3) * (ty + 3), slack = 64;
+    HYAS_HIP(c, hipMalloc((void **)&c->d_occ_tiles, n_tiles * 8 + slack));
+    HYAS_HIP(c, hipMalloc((void **)&c->d_occ_pad, n_pad * 8 + slack));
+    HYAS_HIP(c, hipMemsetAsync((char *)c->d_occ_tiles + n_tiles * 8, 0, slack, c->stream));
+    HYAS_HIP(c, hipMemsetAsync((char *)c->d_occ_pad + n_pad * 8, 0, slack, c->stream));
+    launch_occ_tiles(c->d_charmap, w, h, tx, ty, c->d_occ_tiles, c->d_occ_pad, c->stream);
+    HYAS_HIP(c, hipGetLastError());
+    HYAS_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = HYAS_OK;
     m.occ_tiles = c->d_occ_tiles, m.tiles_x = tx, m.tiles_y = ty;
     // window bitmaps: the box of Lookup::collisionLookup (include/lookup.h:56-60) is bb cells wide and the pose's
     // cell sits at box cell ((int)c.x, (int)c.y) with c = bb / 2 + sub-cell offset (:87-92, :262-263)
@@ -555,12 +544,7 @@ static int upload_footprint_forms(hyas_ctx *c)
                         m8[e] |= bit(i * bb + j) << (8 * i + j);
                 m8[e] |= bit(bb * bb) << 62 | bit(bb * bb + 1) << 63;
             }
-            const uint32_t pitch = tx + 3;
-            std::vector<uint64_t> pad((size_t)pitch * (ty + 3), ~0ull);
-            for (uint32_t y = 0; y < ty; ++y)
-                for (uint32_t x = 0; x < tx; ++x)
-                    pad[(size_t)(y + 1) * pitch + x + 1] = tiles[(size_t)y * tx + x];
-            if ((rc = upload(c, c->d_fp_m8, m8)) != HYAS_OK || (rc = upload(c, c->d_occ_pad, pad)) != HYAS_OK)
+            if ((rc = upload(c, c->d_fp_m8, m8)) != HYAS_OK)
                 return rc;
             m.fp_m8 = c->d_fp_m8, m.occ_pad = c->d_occ_pad;
         }
@@ -1038,89 +1022,100 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     // obstacles + per-key lists
     std::vector<float> xs, ys;
     cell_axes(c, xs, ys);
-    extract_obstacles(c, xs, ys);
-    if (c->quads.size() > 32767)
-        return c->fail(HYAS_ERANGE, "more than 32767 obstacle polygons");
     int rc;
     if ((rc = upload(c, c->d_charmap, c->charmap)) != HYAS_OK)
         return rc;
+    const size_t cells = (size_t)w * h;
+    std::vector<int8_t> occ(cells);
+    {
+        // costmap -> occupancy values on the GPU (src/utility.cpp:185-204)
+        int8_t *d_occ = nullptr;
+        HYAS_HIP(c, hipMalloc((void **)&d_occ, cells));
+        launch_occupancy(c->d_charmap, cells, d_occ, c->stream);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(occ.data(), d_occ, cells, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_occ);
+        if (e != hipSuccess)
+            return hip_fail(c, e, "occupancy values");
+    }
+    extract_obstacles(c, occ, xs, ys);
+    if (c->quads.size() > 32767)
+        return c->fail(HYAS_ERANGE, "more than 32767 obstacle polygons");
     if ((rc = upload(c, c->d_quads, c->quads)) != HYAS_OK)
         return rc;
-    const size_t cells = (size_t)w * h;
     c->cell_off.assign(cells + 1, 0);
     c->cell_idx.clear();
-    // in_range_obstacle_map_.emplace(key, list): the first loop position
-    // that maps to a key keeps it (src/collisiondetection.cpp:345)
+    // in_range_obstacle_map_.emplace(key, list): the first loop position that maps to a key keeps it
+    // (src/collisiondetection.cpp:345); -1: no corner maps to the key
     std::vector<int64_t> owner(cells, -1);
-    for (size_t i = 0; i < xs.size(); ++i)
-        for (size_t j = 0; j < ys.size(); ++j)
-        {
-            uint32_t key = grid_key(m, xs[i], ys[j]);
-            if (key < cells && owner[key] < 0)
-                owner[key] = (int64_t)(i * ys.size() + j);
-        }
-    if (!c->quads.empty())
     {
-        // The range flags (one byte per cell corner and quad) are produced on the GPU in tiles of whole x columns of
-        // at most 64 MiB, so that the staging does not grow with cells x quads.
-        const size_t nq = c->quads.size(), per_col = ys.size() * nq;
-        const size_t cols_per_tile = std::max<size_t>(1, std::min<size_t>(xs.size(), ((size_t)64 << 20) / std::max<size_t>(per_col, 1)));
+        // Lists on the GPU in two passes over (key, polygon): lengths, prefix sum, ids.  Nothing of size
+        // cells x polygons is ever stored.
+        const size_t slack = 64; // kernels fetch list entries in 16-byte blocks, one block ahead
+        const size_t nq = c->quads.size();
         float *d_xs = nullptr, *d_ys = nullptr;
-        uint8_t *d_flags = nullptr;
-        std::vector<uint8_t> flags(cols_per_tile * per_col);
-        // per-key lists, filled tile by tile: lists[key] is written once, by the key's owner position
-        std::vector<std::vector<uint16_t>> lists(cells);
-        std::vector<std::vector<uint32_t>> keys_of_col(xs.size());
-        for (size_t key = 0; key < cells; ++key)
-            if (owner[key] >= 0)
-                keys_of_col[(size_t)owner[key] / ys.size()].push_back((uint32_t)key);
-        hipError_t e = hipSuccess;
+        uint32_t *d_owner = nullptr;
+        unsigned long long *d_total = nullptr, total = 0;
+        std::vector<uint32_t> owner_u(cells);
         rc = upload(c, d_xs, xs);
         if (rc == HYAS_OK)
             rc = upload(c, d_ys, ys);
-        if (rc == HYAS_OK && (e = hipMalloc((void **)&d_flags, flags.size())) != hipSuccess)
-            rc = hip_fail(c, e, "hipMalloc(range flags)");
-        for (size_t i0 = 0; rc == HYAS_OK && i0 < xs.size(); i0 += cols_per_tile)
+        auto step = [&](hipError_t err, const char *what) {
+            if (rc == HYAS_OK && err != hipSuccess)
+                rc = hip_fail(c, err, what);
+            return rc == HYAS_OK;
+        };
+        if (rc == HYAS_OK)
+            step(hipMalloc((void **)&d_owner, cells * sizeof(uint32_t)), "hipMalloc(list owners)");
+        if (rc == HYAS_OK)
+            step(hipMalloc((void **)&d_total, sizeof(unsigned long long)), "hipMalloc(list total)");
+        if (rc == HYAS_OK)
+            step(hipMalloc((void **)&c->d_cell_off, (cells + 1) * sizeof(uint32_t) + slack), "hipMalloc(list offsets)");
+        if (rc == HYAS_OK)
+            step(hipMemsetAsync((char *)c->d_cell_off + (cells + 1) * sizeof(uint32_t), 0, slack, c->stream), "list offsets");
+        if (rc == HYAS_OK)
         {
-            const size_t ni = std::min(cols_per_tile, xs.size() - i0);
-            launch_in_range(c->d_quads, (uint32_t)nq, d_xs + i0, (uint32_t)ni, d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range,
-                            d_flags, c->stream);
-            e = hipGetLastError();
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(flags.data(), d_flags, ni * per_col, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess)
-                e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess)
-            {
-                rc = hip_fail(c, e, "range flags");
-                break;
-            }
-            for (size_t i = i0; i < i0 + ni; ++i)
-                for (uint32_t key : keys_of_col[i])
-                {
-                    const uint8_t *f = &flags[((size_t)owner[key] - i0 * ys.size()) * nq];
-                    for (size_t q = 0; q < nq; ++q)
-                        if (f[q])
-                            lists[key].push_back((uint16_t)q);
-                }
+            launch_in_range_lists(m, c->d_quads, (uint32_t)nq, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range,
+                                  d_owner, c->d_cell_off, nullptr, d_total, 0, c->stream);
+            step(hipGetLastError(), "in-range list lengths");
         }
-        if (d_xs)
-            (void)hipFree(d_xs);
-        if (d_ys)
-            (void)hipFree(d_ys);
-        if (d_flags)
-            (void)hipFree(d_flags);
+        if (rc == HYAS_OK)
+            step(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, c->stream), "in-range list lengths");
+        if (rc == HYAS_OK)
+            step(hipStreamSynchronize(c->stream), "in-range list lengths");
+        if (rc == HYAS_OK && total >= (1ull << 32))
+            rc = c->fail(HYAS_ERANGE, "the in-range obstacle lists hold 2^32 entries or more");
+        if (rc == HYAS_OK)
+            step(hipMalloc((void **)&c->d_cell_idx, (size_t)total * sizeof(uint16_t) + slack), "hipMalloc(list entries)");
+        if (rc == HYAS_OK)
+            step(hipMemsetAsync((char *)c->d_cell_idx + (size_t)total * sizeof(uint16_t), 0, slack, c->stream), "list entries");
+        if (rc == HYAS_OK)
+        {
+            launch_in_range_lists(m, c->d_quads, (uint32_t)nq, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range,
+                                  d_owner, c->d_cell_off, c->d_cell_idx, d_total, 1, c->stream);
+            step(hipGetLastError(), "in-range lists");
+        }
+        // the host keeps copies: list pruning, the adaptive maps and the getters read them
+        c->cell_idx.resize((size_t)total);
+        if (rc == HYAS_OK)
+            step(hipMemcpyAsync(c->cell_off.data(), c->d_cell_off, (cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "in-range lists");
+        if (rc == HYAS_OK && total)
+            step(hipMemcpyAsync(c->cell_idx.data(), c->d_cell_idx, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream), "in-range lists");
+        if (rc == HYAS_OK)
+            step(hipMemcpyAsync(owner_u.data(), d_owner, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "in-range lists");
+        if (rc == HYAS_OK)
+            step(hipStreamSynchronize(c->stream), "in-range lists");
+        for (void *p : {(void *)d_xs, (void *)d_ys, (void *)d_owner, (void *)d_total})
+            if (p)
+                (void)hipFree(p);
         if (rc != HYAS_OK)
             return rc;
         for (size_t key = 0; key < cells; ++key)
-        {
-            c->cell_off[key] = (uint32_t)c->cell_idx.size();
-            c->cell_idx.insert(c->cell_idx.end(), lists[key].begin(), lists[key].end());
-        }
-        c->cell_off[cells] = (uint32_t)c->cell_idx.size();
+            owner[key] = owner_u[key] == 0xFFFFFFFFu ? -1 : (int64_t)owner_u[key];
     }
-    if ((rc = upload(c, c->d_cell_off, c->cell_off)) != HYAS_OK || (rc = upload(c, c->d_cell_idx, c->cell_idx)) != HYAS_OK)
-        return rc;
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
     m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx;
     if (m.ad_mode != 0 && (rc = build_adaptive_maps(c, xs, ys, owner)) != HYAS_OK)
@@ -1554,5 +1549,16 @@ int hyas_in_range_count(const hyas_ctx *c, uint32_t key)
     if (!c || !c->have_map || c->grid_only || key >= (uint64_t)c->w * c->h || (size_t)key + 1 >= c->cell_off.size())
         return -1;
     return (int)(c->cell_off[key + 1] - c->cell_off[key]);
+}
+int hyas_in_range_list(const hyas_ctx *c, uint32_t key, float *out, size_t cap)
+{
+    const int n = hyas_in_range_count(c, key);
+    for (int i = 0; i < n && (size_t)i < cap && out; ++i)
+    {
+        const Quad &q = c->quads[c->cell_idx[c->cell_off[key] + i]];
+        for (int k = 0; k < 4; ++k)
+            out[i * 8 + 2 * k] = q.vx[k], out[i * 8 + 2 * k + 1] = q.vy[k];
+    }
+    return n;
 }
 }

@@ -22,8 +22,12 @@ struct StepIn
 #define ROUND_TAG_CANDIDATE 2u // hyas_succ::pad, high byte: 1 + index of the motion-set entry (fixed motion set) the successor comes from
 
 void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
-void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
-                     uint8_t *flags, hipStream_t s);
+// map ingest: occupancy values, occupancy bit tiles (padded may be null), per-key in-range lists.
+void launch_occupancy(const uint8_t *cost, size_t n, int8_t *occ, hipStream_t s);
+void launch_occ_tiles(const uint8_t *cost, uint32_t w, uint32_t h, uint32_t tx, uint32_t ty, uint64_t *tiles, uint64_t *padded, hipStream_t s);
+// pass 0: owner[key] (w*h entries), off[0..w*h] = offsets of the lists, *total = their sum; pass 1: idx filled (total entries).
+void launch_in_range_lists(const DevMap &m, const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
+                           uint32_t *owner, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s);
 void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,
                            float *out, hipStream_t s);
 void launch_min_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float *out, hipStream_t s);

@@ -397,20 +397,144 @@ __global__ void __launch_bounds__(1024) k_collision_footprint_m8(DevMap m, int h
 }
 
 // --------------------------------------------------------------- map ingest
-// flags[c * n_quads + q] = 1 iff quad q is within `range` of the cell corner
-// (xs[c / nys], ys[c % nys]): the test of src/collisiondetection.cpp:335-343.
-__global__ void __launch_bounds__(256) k_in_range(const Quad *__restrict__ quads, uint32_t n_quads,
-                                                  const float *__restrict__ xs, uint32_t nxs,
-                                                  const float *__restrict__ ys, uint32_t nys, float range,
-                                                  uint8_t *__restrict__ flags)
+// nav_msgs::OccupancyGrid value of every costmap cell (src/utility.cpp:185-204): 0 free, 99 inscribed, 100 lethal,
+// -1 unknown, 1..98 in between.
+__global__ void __launch_bounds__(256) k_occupancy(const uint8_t *__restrict__ cost, size_t n, int8_t *__restrict__ occ)
 {
-    const size_t total = (size_t)nxs * nys * n_quads;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const int c = cost[i];
+        occ[i] = (int8_t)(c == 0 ? 0 : c == 253 ? 99 : c == 254 ? 100 : c == 255 ? -1 : 1 + (97 * (c - 1)) / 251);
+    }
+}
+
+// Occupancy bits of the footprint-list test: one 64-bit word per 8 x 8 cells (bit 8 * (y & 7) + (x & 7); cost >= 250 or
+// beyond the grid: set), once as [tiles_y][tiles_x] and once with a border of all-ones tiles (one tile left and above,
+// two right and below), pitch tiles_x + 3.  One thread per word of the padded form.
+__global__ void __launch_bounds__(256) k_occ_tiles(const uint8_t *__restrict__ cost, uint32_t w, uint32_t h, uint32_t tx, uint32_t ty,
+                                                   uint64_t *__restrict__ tiles, uint64_t *__restrict__ padded)
+{
+    const uint32_t pitch = tx + 3;
+    const size_t total = (size_t)pitch * (ty + 3);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
     {
-        uint32_t q = (uint32_t)(i % n_quads);
-        size_t c = i / n_quads;
-        F2 p = f2(xs[c / nys], ys[c % nys]);
-        flags[i] = dist_quad_point(quads[q], p) < range ? 1 : 0;
+        const uint32_t py = (uint32_t)(i / pitch), px = (uint32_t)(i % pitch);
+        uint64_t bits = ~0ull;
+        if (px >= 1 && px <= tx && py >= 1 && py <= ty)
+        {
+            const uint32_t x0 = (px - 1) * 8, y0 = (py - 1) * 8;
+            bits = 0;
+            for (uint32_t r = 0; r < 8; ++r)
+                for (uint32_t q = 0; q < 8; ++q)
+                {
+                    const uint32_t x = x0 + q, y = y0 + r;
+                    if (x >= w || y >= h || cost[(size_t)y * w + x] >= 250)
+                        bits |= 1ull << (8 * r + q);
+                }
+            tiles[(size_t)(py - 1) * tx + (px - 1)] = bits;
+        }
+        if (padded)
+            padded[i] = bits;
+    }
+}
+
+// in_range_obstacle_map_.emplace(key, list) keeps the list of the FIRST loop position (x outer, y inner) that maps to
+// a key (src/collisiondetection.cpp:327-348): owner[key] = min position i * nys + j; 0xFFFFFFFF where no corner maps.
+__global__ void __launch_bounds__(256) k_cell_owner(DevMap m, const float *__restrict__ xs, uint32_t nxs, const float *__restrict__ ys, uint32_t nys,
+                                                    uint32_t *__restrict__ owner)
+{
+    const size_t total = (size_t)nxs * nys;
+    const uint32_t cells = m.w * m.h;
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < total; c += (size_t)gridDim.x * blockDim.x)
+    {
+        const uint32_t key = grid_key(m, xs[c / nys], ys[c % nys]);
+        if (key < cells)
+            atomicMin(&owner[key], (uint32_t)c);
+    }
+}
+
+// The in-range list of every grid key (src/collisiondetection.cpp:335-345): the obstacle polygons nearer than `range`
+// to the key's owner corner, in obstacle order.  One wave per key, 64 polygons per pass, positions inside a pass by
+// ballot.  FILL = false counts (off[key] = list length), FILL = true writes the ids behind off[key].
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_in_range_lists(const Quad *__restrict__ quads, uint32_t n_quads, const float *__restrict__ xs,
+                                                        const float *__restrict__ ys, uint32_t nys, const uint32_t *__restrict__ owner, uint32_t cells,
+                                                        float range, uint32_t *__restrict__ off, uint16_t *__restrict__ idx)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    for (size_t key = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6); key < cells; key += waves)
+    {
+        const uint32_t pos = owner[key];
+        uint32_t n = 0;
+        if (pos != 0xFFFFFFFFu)
+        {
+            const F2 p = f2(xs[pos / nys], ys[pos % nys]);
+            const uint32_t base = FILL ? off[key] : 0u;
+            for (uint32_t q0 = 0; q0 < n_quads; q0 += 64)
+            {
+                const uint32_t q = q0 + lane;
+                const bool hit = q < n_quads && dist_quad_point(quads[q], p) < range;
+                const unsigned long long mask = __ballot(hit);
+                if (FILL && hit)
+                    idx[base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)q;
+                n += (uint32_t)__popcll(mask);
+            }
+        }
+        if (!FILL && lane == 0)
+            off[key] = n;
+    }
+}
+
+// In-place exclusive prefix sum of v[0..n) with the total in v[n] and, as 64 bits, in *total.  One workgroup of 1024
+// lanes, four entries per lane and pass.
+__global__ void __launch_bounds__(1024) k_exclusive_scan_u32(uint32_t *__restrict__ v, size_t n, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carry_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n; base += 4096)
+    {
+        const size_t i0 = base + 4 * (size_t)threadIdx.x;
+        uint32_t a[4];
+        unsigned long long mine = 0;
+        for (int k = 0; k < 4; ++k)
+        {
+            a[k] = i0 + k < n ? v[i0 + k] : 0u;
+            mine += a[k];
+        }
+        unsigned long long incl = mine;
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const unsigned long long up = __shfl_up(incl, d, 64);
+            if ((int)lane >= d)
+                incl += up;
+        }
+        if (lane == 63)
+            wave_sum[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (uint32_t k = 0; k < wave; ++k)
+            before += wave_sum[k];
+        unsigned long long run = before + incl - mine;
+        for (int k = 0; k < 4; ++k)
+        {
+            if (i0 + k < n)
+                v[i0 + k] = (uint32_t)run;
+            run += a[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry_s = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        v[n] = (uint32_t)carry_s;
+        *total = carry_s;
     }
 }
 
@@ -1908,13 +2032,35 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
         hipLaunchKernelGGL(k_collision_polygon, dim3(grid_for(n)), dim3(256), 0, s, m, xyt, pred_xy, n, out);
 }
 
-void launch_in_range(const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
-                     uint8_t *flags, hipStream_t s)
+void launch_occupancy(const uint8_t *cost, size_t n, int8_t *occ, hipStream_t s)
 {
-    size_t total = (size_t)nxs * nys * n_quads;
-    if (total == 0)
+    if (n)
+        hipLaunchKernelGGL(k_occupancy, dim3(grid_for(n)), dim3(256), 0, s, cost, n, occ);
+}
+
+void launch_occ_tiles(const uint8_t *cost, uint32_t w, uint32_t h, uint32_t tx, uint32_t ty, uint64_t *tiles, uint64_t *padded, hipStream_t s)
+{
+    const size_t total = (size_t)(tx + 3) * (ty + 3);
+    hipLaunchKernelGGL(k_occ_tiles, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, cost, w, h, tx, ty, tiles, padded);
+}
+
+void launch_in_range_lists(const DevMap &m, const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
+                           uint32_t *owner, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s)
+{
+    const uint32_t cells = m.w * m.h;
+    if (cells == 0)
         return;
-    hipLaunchKernelGGL(k_in_range, dim3(grid_for(total)), dim3(256), 0, s, quads, n_quads, xs, nxs, ys, nys, range, flags);
+    const int grid = grid_for(cells, 4, 256 * 32); // four waves (keys) per workgroup
+    if (pass == 0)
+    {
+        hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(cells)), dim3(256), 0, s, owner, (size_t)cells, 0xFFFFFFFFu);
+        if ((size_t)nxs * nys)
+            hipLaunchKernelGGL(k_cell_owner, dim3(grid_for((size_t)nxs * nys)), dim3(256), 0, s, m, xs, nxs, ys, nys, owner);
+        hipLaunchKernelGGL(k_in_range_lists<false>, dim3(grid), dim3(256), 0, s, quads, n_quads, xs, ys, nys, owner, cells, range, off, idx);
+        hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, off, (size_t)cells, total);
+    }
+    else
+        hipLaunchKernelGGL(k_in_range_lists<true>, dim3(grid), dim3(256), 0, s, quads, n_quads, xs, ys, nys, owner, cells, range, off, idx);
 }
 
 void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,

@@ -1,0 +1,64 @@
+"""Map ingest timing: hyas_set_costmap (occupancy values, obstacle polygons, per-key in-range lists, pruned lists,
+footprint forms; no heuristic table) and hyas_set_grid (occupancy bit tiles) on maps of growing size.
+
+    python profiles/ingest_workload.py [--out FILE]        (HYAS_LIB=<other libhyas.so> times another build)
+
+Prints one JSON line: per map the cells, obstacle polygons, list entries and the median seconds of five calls.
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from path_planner_amd import Hyas, hot_path_params  # noqa: E402
+from path_planner_amd.sharding import load_map  # noqa: E402
+
+
+def random_costmap(w, h, seed, share):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((h, w), np.uint8)
+    m[rng.random((h, w)) < share] = 254
+    return m
+
+
+def median_seconds(fn, reps=5):
+    fn()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        t.append(time.perf_counter() - t0)
+    return float(np.median(t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out")
+    a = ap.parse_args()
+    h = Hyas(hot_path_params(position_resolution=1), device=0)
+    rows = []
+    maps = [("map_maze 50x50", load_map("map_maze")), ("map_large 180x60", load_map("map_large")),
+            ("random 400x300, 4% occupied", random_costmap(400, 300, 1, 0.04)),
+            ("random 800x600, 3% occupied", random_costmap(800, 600, 2, 0.03))]
+    for name, m in maps:
+        s = median_seconds(lambda: h.set_costmap(m, build_table=False))
+        n_quads = h.obstacles().shape[0]
+        entries = sum(h.in_range_count(k) for k in range(0, m.size, max(1, m.size // 4096))) * max(1, m.size // 4096)
+        rows.append({"map": name, "cells": int(m.size), "polygons": int(n_quads), "list_entries_estimate": int(entries),
+                     "cell_polygon_pairs": int(m.size) * int(n_quads), "set_costmap_s": s})
+    g = random_costmap(4096, 4096, 1, 0.10)
+    rows.append({"map": "grid 4096x4096 (hyas_set_grid)", "cells": int(g.size), "set_grid_s": median_seconds(lambda: h.set_grid(g))})
+    line = json.dumps({"workload": "map ingest", "rows": rows})
+    print(line)
+    if a.out:
+        Path(a.out).write_text(line + "\n")
+
+
+if __name__ == "__main__":
+    main()

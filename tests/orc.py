@@ -134,7 +134,7 @@ class Oracle:
         L.orc_plan_many.restype = C.c_double
         for f in ("orc_collision_batch", "orc_expand_batch", "orc_shot_batch", "orc_flood", "orc_table_build",
                   "orc_table_lookup", "orc_plan", "orc_get_path", "orc_get_expanded", "orc_footprint_table",
-                  "orc_get_obstacles", "orc_in_range_count", "orc_num_obstacles", "orc_num_successors",
+                  "orc_get_obstacles", "orc_in_range_count", "orc_in_range_list", "orc_num_obstacles", "orc_num_successors",
                   "orc_table_dims", "orc_build_table", "orc_rs_path", "orc_rs_sample", "orc_dubins",
                   "orc_dubins_sample", "orc_plan_many", "orc_twod_size", "orc_set_grid", "orc_plan_r", "orc_shortcut", "orc_expand_batch_from",
                   "orc_step_steer_pairs", "orc_adaptive_cell"):
@@ -169,6 +169,12 @@ class Oracle:
 
     def in_range_count(self, key):
         return self.L.orc_in_range_count(self.h, C.c_uint32(key))
+
+    def in_range_list(self, key):
+        n = max(0, self.in_range_count(key))
+        out = np.zeros((n, 8), np.float32)
+        self.L.orc_in_range_list(self.h, C.c_uint32(key), out.ctypes.data_as(C.c_void_p), C.c_size_t(n))
+        return out
 
     def collision(self, xyt, pred_xy=None, mode=0):
         xyt = np.ascontiguousarray(xyt, np.float32)

@@ -68,6 +68,40 @@ def test_obstacles_and_lists(parking):
         assert max(0, p.o.in_range_count(key)) == p.h.in_range_count(key), key
 
 
+def _random_costmap(w, h, seed, share=0.12):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((h, w), np.uint8)
+    hit = rng.random((h, w)) < share
+    m[hit] = rng.choice(np.array([1, 60, 128, 252, 253, 254, 255], np.uint8), int(hit.sum()))
+    return m
+
+
+def test_in_range_list_contents(parking, maze):
+    """Every grid key's obstacle list, polygon by polygon in list order (the lists are assembled on the GPU: lengths,
+    prefix sum, ids), on the shipped maps and on a random costmap of every cost class with half-metre cells, a shifted
+    origin, more than 4096 keys and several hundred polygons."""
+    for p in (parking, maze):
+        for key in range(p.W * p.H):
+            a, b = p.o.in_range_list(key), p.h.in_range_list(key)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), key
+    m = _random_costmap(96, 70, 5)
+    po, ph = _params(position_resolution=1, obstacle_detection_range=2.5)
+    o, h = orc.Oracle(po), Hyas(ph)
+    o.set_costmap(m, 0.5, -7.25, 3.5, build_table=False)
+    h.set_costmap(m, 0.5, -7.25, 3.5, build_table=False)
+    a, b = o.obstacles(), h.obstacles()
+    assert a.shape[0] > 300 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    longest = 0
+    for key in range(96 * 70):
+        a, b = o.in_range_list(key), h.in_range_list(key)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), key
+        longest = max(longest, a.shape[0])
+    assert longest > 8
+    rng = np.random.default_rng(6)
+    xyt = np.stack([rng.uniform(-7.25, 40.75, 20000), rng.uniform(3.5, 38.5, 20000), rng.uniform(0, 6.28, 20000)], 1).astype(np.float32)
+    assert np.array_equal(o.collision(xyt), h.collision(xyt))
+
+
 def test_footprint_table(parking):
     a, b = parking.o.footprint_table(), parking.h.footprint_table()
     assert a.shape == b.shape
