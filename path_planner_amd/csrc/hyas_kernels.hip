@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, 
         const double q1[3] = {(double)xs[i], (double)ys[j], (double)ts[k]};
         double x, y, phi;
         rs::normalise(q0, q1, rho, x, y, phi);
-        out[e] = (float)(rho * rs::solve_serial(x, y, phi).total);
+        out[e] = (float)(rho * rs::solve_hoisted(x, y, phi).total);
     }
 }
 

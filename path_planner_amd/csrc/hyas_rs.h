@@ -75,9 +75,9 @@ struct TUV
     double t, u, v;
     int ok;
 };
-RS_HD bool base_formula_body(int f, double x, double y, double phi, double &t, double &u, double &v)
+// (sp, cp): sine and cosine of phi
+RS_HD bool base_formula_body_sc(int f, double x, double y, double phi, double sp, double cp, double &t, double &u, double &v)
 {
-    const double sp = hy_sin(phi), cp = hy_cos(phi);
     switch (f)
     {
     case 0: // LpSpLp (8.1)
@@ -190,11 +190,23 @@ RS_HD bool base_formula_body(int f, double x, double y, double phi, double &t, d
     }
 }
 
+RS_HD bool base_formula_body(int f, double x, double y, double phi, double &t, double &u, double &v)
+{
+    return base_formula_body_sc(f, x, y, phi, hy_sin(phi), hy_cos(phi), t, u, v);
+}
+
 RS_HDC TUV base_formula_call(int f, double x, double y, double phi)
 {
     TUV r;
     r.t = r.u = r.v = 0;
     r.ok = base_formula_body(f, x, y, phi, r.t, r.u, r.v) ? 1 : 0;
+    return r;
+}
+RS_HDC TUV base_formula_call_sc(int f, double x, double y, double phi, double sp, double cp)
+{
+    TUV r;
+    r.t = r.u = r.v = 0;
+    r.ok = base_formula_body_sc(f, x, y, phi, sp, cp, r.t, r.u, r.v) ? 1 : 0;
     return r;
 }
 RS_HD bool base_formula(int f, double x, double y, double phi, double &t, double &u, double &v)
@@ -299,13 +311,13 @@ RS_HD bool candidate(int c, double x, double y, double phi, Path &p, double &L)
 // lanes of one wave then spend the time of the longest form instead of the sum of the forms they hold.  Every
 // candidate performs exactly the operations of base_formula_body() on exactly the same values, so the results are
 // equal bit for bit; arguments of a candidate already known to fail are replaced by harmless ones.
-RS_HD bool candidate_staged(int c, double x, double y, double phi, Path &p, double &L)
+// (s0, c0): sine and cosine of phi; (sp, cp): of the candidate's own angle, -phi when exactly one of its two
+// symmetries is on, else phi.
+RS_HD bool candidate_staged_sc(int c, double x, double y, double phi, double s0, double c0, double sp, double cp, Path &p, double &L)
 {
     int formula, backwards, family, word, layout;
     group_info(c >> 2, formula, backwards, family, word, layout);
     const int sym = c & 3;
-    double s0, c0;
-    hy_sincos(phi, &s0, &c0);
     double X = x, Y = y;
     if (backwards) // :205, :400
     {
@@ -316,8 +328,6 @@ RS_HD bool candidate_staged(int c, double x, double y, double phi, Path &p, doub
     const double ax = flip ? -X : X;
     const double ay = reflect ? -Y : Y;
     const double aphi = (flip != reflect) ? -phi : phi;
-    double sp, cp;
-    hy_sincos(aphi, &sp, &cp);
 
     // stage 1: the polar form every closed form starts from
     const bool plus = formula == 1 || formula == 3 || formula == 4 || formula == 6 || formula == 7;
@@ -481,6 +491,15 @@ RS_HD bool candidate_staged(int c, double x, double y, double phi, Path &p, doub
     return true;
 }
 
+RS_HD bool candidate_staged(int c, double x, double y, double phi, Path &p, double &L)
+{
+    const int sym = c & 3;
+    double s0, c0, sp, cp;
+    hy_sincos(phi, &s0, &c0);
+    hy_sincos((((sym & 1) != 0) != ((sym & 2) != 0)) ? -phi : phi, &sp, &cp);
+    return candidate_staged_sc(c, x, y, phi, s0, c0, sp, cp, p, L);
+}
+
 // Starting bound of each family's scan: path.length() minus the fixed quarter
 // turns its comparison leaves out (:348, :470).
 RS_HD double family_bound(int fam, double best_total)
@@ -514,6 +533,41 @@ RS_HD Path solve_serial(double x, double y, double phi)
             Path p;
             double L;
             if (candidate(c, x, y, phi, p, L) && lmin > L)
+            {
+                best = p;
+                lmin = L;
+            }
+        }
+    }
+    return best;
+}
+
+// The same walk with the two sine/cosine pairs all 44 candidates use (of phi and of -phi) taken once: what the
+// heuristic-table kernel runs, one goal per lane (29.7 -> 22.7 ms for 79 M entries).  Neighbouring table entries fail
+// the same candidates at the same tests, so the plain form's early exits cost little there: the side-by-side form,
+// which evaluates every candidate to the end, measured 32.5 ms in that kernel, and sharing the polar forms of
+// (xi, eta) between candidates as well (twelve serve 28 candidates) 29.5 ms, since it needs the walk unrolled.
+RS_HD Path solve_hoisted(double x, double y, double phi)
+{
+    const double s_pos = hy_sin(phi), c_pos = hy_cos(phi), s_neg = hy_sin(-phi), c_neg = hy_cos(-phi);
+    const double xb = x * c_pos + y * s_pos, yb = x * s_pos - y * c_pos; // the backwards frame, :205, :400
+    Path best = empty_path();
+    for (int fam = 0; fam < RS_NUM_FAMILIES; ++fam)
+    {
+        double lmin = family_bound(fam, best.total);
+        for (int c = family_first(fam); c < family_first(fam + 1); ++c)
+        {
+            int formula, backwards, family, word, layout;
+            group_info(c >> 2, formula, backwards, family, word, layout);
+            const bool flip = (c & 1) != 0, reflect = (c & 2) != 0, neg = flip != reflect;
+            const double X = backwards ? xb : x, Y = backwards ? yb : y;
+            const TUV r = base_formula_call_sc(formula, flip ? -X : X, reflect ? -Y : Y, neg ? -phi : phi, neg ? s_neg : s_pos, neg ? c_neg : c_pos);
+            if (!r.ok)
+                continue;
+            Path p;
+            double L;
+            candidate_tail(family, word, layout, flip, reflect, r.t, r.u, r.v, p, L);
+            if (lmin > L)
             {
                 best = p;
                 lmin = L;

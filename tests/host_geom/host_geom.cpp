@@ -108,6 +108,23 @@ extern "C" long hg_rs_staged_mismatches(const double *xyphi, int n, long *valid_
     return bad;
 }
 
+// rs::solve_hoisted (what the table kernel runs: sine and cosine of +-phi taken once for all candidates) against
+// rs::solve_serial (the reference's walk, src/ReedsShepp.cpp:494-503): goals whose winning path differs in any bit.
+extern "C" long hg_rs_solve_uniform_mismatches(const double *xyphi, int n)
+{
+    long bad = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const rs::Path a = rs::solve_serial(xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2]);
+        const rs::Path b = rs::solve_hoisted(xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2]);
+        bool same = a.type == b.type && std::memcmp(&a.total, &b.total, 8) == 0;
+        for (int k = 0; k < 5; k++)
+            same = same && std::memcmp(&a.len[k], &b.len[k], 8) == 0;
+        bad += !same;
+    }
+    return bad;
+}
+
 // hy_sincos against hy_sin and hy_cos: number of arguments where a bit differs.
 extern "C" long hg_sincos_mismatches(const double *x, int n)
 {

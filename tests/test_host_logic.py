@@ -92,6 +92,9 @@ def test_side_by_side_reeds_shepp_candidates_equal_the_plain_form(host_geom):
     bad = host_geom.hg_rs_staged_mismatches(g.ctypes.data_as(C.c_void_p), n, C.byref(valid))
     assert valid.value > 4 * n  # several candidates exist for a typical goal
     assert bad == 0
+    # the table kernel's walk over the side-by-side candidates picks the reference walk's path
+    host_geom.hg_rs_solve_uniform_mismatches.restype = C.c_long
+    assert host_geom.hg_rs_solve_uniform_mismatches(g.ctypes.data_as(C.c_void_p), n) == 0
     host_geom.hg_rs_interp_mismatches.restype = C.c_long
     assert host_geom.hg_rs_interp_mismatches(g.ctypes.data_as(C.c_void_p), 20000, 40, C.c_double(0.35)) == 0
     x = np.concatenate([rng.uniform(-100, 100, 200000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, math.pi / 4, -math.pi / 4, 1e5, -1e5]])
