@@ -51,7 +51,7 @@ typedef struct hyas_params
     float vehicle_width;              /* 1 */
     float vehicle_length;             /* 2 */
     float obstacle_detection_range;   /* 5 */
-    int32_t map_boundary_obstacle;    /* 0 (only 0 is supported) */
+    int32_t map_boundary_obstacle;    /* 0; 1: four rectangles around the grid join the obstacles (src/collisiondetection.cpp:305-308, :1223-1240) */
     /* ParameterHybridAStar */
     int32_t number_of_successors;     /* 3 */
     int32_t adaptive_steering_angle_and_step_size; /* 0; wins over adaptive_step_size when both are set */

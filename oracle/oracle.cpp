@@ -1400,6 +1400,16 @@ struct Ctx
             }
             x = x + resolution_;
         }
+        if (P.map_boundary_obstacle)
+            AddMapBoundaryAsObstacle(obstacle_vec_);
+    }
+    // src/collisiondetection.cpp:1223-1240: the rectangles are given in cells (grid_ptr_->info.width / height)
+    void AddMapBoundaryAsObstacle(std::vector<Polygon> &obstacle_vec)
+    {
+        obstacle_vec.push_back(CreatePolygon(V2{0, -1}, (float)cm.w, 1));
+        obstacle_vec.push_back(CreatePolygon(V2{(float)cm.w, -1}, 1, (float)(cm.h + 2)));
+        obstacle_vec.push_back(CreatePolygon(V2{-1, (float)cm.h}, (float)(cm.w + 2), 1));
+        obstacle_vec.push_back(CreatePolygon(V2{-1, 0}, 1, (float)cm.h));
     }
     // src/collisiondetection.cpp:319-354
     void SetInRangeObstacle()

@@ -314,6 +314,22 @@ static void extract_obstacles(hyas_ctx *c, const std::vector<int8_t> &occ, const
             else
                 c->quads.push_back(cur);
         }
+    if (c->P.map_boundary_obstacle)
+    {
+        // CollisionDetection::AddMapBoundaryAsObstacle, src/collisiondetection.cpp:1223-1240: four rectangles around
+        // the grid, given in cells whatever the resolution and the origin are; CreatePolygon(origin, width, height),
+        // src/utility.cpp:457-474
+        auto add = [&](float x, float y, float width, float height) {
+            const float vx[4] = {x, width + x, width + x, x};
+            const float vy[4] = {y, y, y + height, y + height};
+            c->quads.push_back(make_quad(vx, vy));
+        };
+        const uint32_t w = c->w, h = c->h;
+        add(0.f, -1.f, (float)w, 1.f);
+        add((float)w, -1.f, 1.f, (float)(h + 2));
+        add(-1.f, (float)h, (float)(w + 2), 1.f);
+        add(-1.f, 0.f, 1.f, (float)h);
+    }
 }
 
 // --------------------------------------------------- footprint-list table
@@ -616,8 +632,6 @@ static bool params_ok(const hyas_params *p, std::string &why)
         why = "consider_steering_angle_range_for_obstacle_density is not supported (the obstacle density is taken per grid cell)";
     else if ((p->adaptive_steering_angle_and_step_size || p->adaptive_step_size) && !(p->obstacle_detection_range > 0))
         why = "the adaptive modes need a positive obstacle_detection_range";
-    else if (p->map_boundary_obstacle)
-        why = "map_boundary_obstacle is not supported";
     else if (p->headings < 1 || p->headings > 720 || p->position_resolution < 1 || p->position_resolution > 64)
         why = "headings / position_resolution out of range";
     else if (p->curve_type != HYAS_CURVE_RS && p->curve_type != HYAS_CURVE_DUBINS && p->curve_type != HYAS_CURVE_BEZIER)
@@ -1014,6 +1028,9 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     // the on-line / on-segment snaps act within 1e-3 rad or 1e-3 m of an edge
     // no longer than the map diagonal
     m.cull_margin = (float)(0.01 + 2e-3 * std::sqrt((double)w * w + (double)h * h) * res);
+    if (c->P.map_boundary_obstacle) // the boundary rectangles' corners lie up to a rectangle's length beyond the detection range
+        m.cull_margin = (float)(0.01 + 2e-3 * (std::sqrt((double)w * w + (double)h * h) * res + (double)w + (double)h + 4 +
+                                                 std::max(0.0, (double)c->P.obstacle_detection_range)));
     m.pr = c->P.position_resolution, m.headings = c->P.headings;
     m.twod_size = (uint32_t)c->twod_size;
     m.delta_heading = (float)(2 * HY_PI / (double)(float)c->P.headings); // src/lookup_table.cpp:127

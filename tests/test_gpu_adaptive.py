@@ -45,6 +45,21 @@ def test_adaptive_maps(oracle_built, name, res, ox, oy):
     assert seen >= p.W * p.H - 1
 
 
+def test_adaptive_modes_with_map_boundary_obstacle(oracle_built):
+    """The boundary rectangles of map_boundary_obstacle = 1 take part in the sweeps and the density like any obstacle."""
+    p = Pair("map_parking", position_resolution=1, max_iterations=300, map_boundary_obstacle=1, **COMBINED)
+    for key in range(p.W * p.H):
+        want = p.o.adaptive_cell(key, cut=True)
+        md, de, rng = p.h.adaptive_cell(key)
+        if want is None:
+            assert len(rng) == 0 and de == 0
+            continue
+        assert np.float32(want[0]).view(np.uint32) == np.float32(md).view(np.uint32), key
+        assert np.float32(want[1]).view(np.uint32) == np.float32(de).view(np.uint32), key
+        assert want[2].tobytes() == rng.tobytes(), (key, want[2], rng)
+    _plan_compare(p, p.free_poses(16, 41), p.free_poses(16, 42))
+
+
 def _starts(p, n, seed):
     s = np.zeros(n, orc.GOAL_DT)
     xyt = p.free_poses(n, seed)

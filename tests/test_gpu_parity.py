@@ -102,6 +102,38 @@ def test_in_range_list_contents(parking, maze):
     assert np.array_equal(o.collision(xyt), h.collision(xyt))
 
 
+def test_map_boundary_obstacle(oracle_built):
+    """map_boundary_obstacle = 1 (CollisionDetection::AddMapBoundaryAsObstacle, src/collisiondetection.cpp:1223-1240):
+    four rectangles around the grid, in cells whatever resolution and origin are, join the obstacle polygons behind the
+    extracted ones; polygons, lists, verdicts near the border and whole searches against the oracle."""
+    p = Pair("map_parking", position_resolution=2, max_iterations=200, map_boundary_obstacle=1)
+    q = Pair("map_parking", position_resolution=2, max_iterations=200)
+    a, b = p.o.obstacles(), p.h.obstacles()
+    assert a.shape[0] == q.h.obstacles().shape[0] + 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(b[-4], np.array([0, -1, p.W, -1, p.W, 0, 0, 0], np.float32))
+    for key in range(p.W * p.H):
+        a, b = p.o.in_range_list(key), p.h.in_range_list(key)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), key
+    xyt = p.poses(40000, 31, margin=0.5)
+    rng = np.random.default_rng(32)
+    xyt[:10000, 0] = rng.uniform(0, 1.2, 10000)  # along the left border
+    xyt[10000:20000, 1] = rng.uniform(p.H - 1.2, p.H, 10000)  # along the top border
+    pred = (xyt[:, :2] + rng.uniform(-0.3, 0.3, (xyt.shape[0], 2))).astype(np.float32)
+    want = p.o.collision(xyt, pred)
+    assert np.array_equal(want, p.h.collision(xyt, pred))
+    assert (want != q.o.collision(xyt, pred)).sum() > 20  # the boundary rectangles decide verdicts of their own
+    s, g = p.free_poses(24, 33), p.free_poses(24, 34)
+    _plan_compare(p, s, g)
+    # half-metre cells and a shifted origin: the rectangles stay where the reference puts them
+    r = Pair("map_basic", res=0.5, ox=-3.25, oy=2.5, position_resolution=1, max_iterations=60, map_boundary_obstacle=1,
+             vehicle_width=0.5, vehicle_length=1.0, min_turning_radius=2.0, cd_min_turning_radius=2.0)
+    assert np.array_equal(r.o.obstacles().view(np.uint32), r.h.obstacles().view(np.uint32))
+    xyt = r.poses(30000, 35, margin=0.7)
+    pred = (xyt[:, :2] + np.float32(0.07)).astype(np.float32)
+    assert np.array_equal(r.o.collision(xyt, pred), r.h.collision(xyt, pred))
+    _plan_compare(r, r.free_poses(12, 36), r.free_poses(12, 37))
+
+
 def test_footprint_table(parking):
     a, b = parking.o.footprint_table(), parking.h.footprint_table()
     assert a.shape == b.shape
@@ -464,7 +496,7 @@ def test_abi_error_behaviour():
     L = hl.load_library()
     # unsupported parameter sets are refused at creation
     for kw in (dict(adaptive_step_size=1, consider_steering_angle_range_for_obstacle_density=1),
-               dict(adaptive_steering_angle_and_step_size=1, obstacle_detection_range=0.0), dict(map_boundary_obstacle=1),
+               dict(adaptive_steering_angle_and_step_size=1, obstacle_detection_range=0.0),
                dict(curve_type=3), dict(curve_type=-1),
                dict(vehicle_width=-1.0), dict(min_turning_radius=0.0), dict(number_of_successors=0), dict(headings=0)):
         p = hl.hot_path_params(**kw)
