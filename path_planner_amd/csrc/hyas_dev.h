@@ -461,6 +461,17 @@ HD bool vehicle_hits_quad(F2 c0, F2 c1, F2 c2, F2 c3, const Quad &q)
     return vehicle_hits_verts(c0, c1, c2, c3, qv(q, 0), qv(q, 1), qv(q, 2), qv(q, 3));
 }
 
+// The part of the pose test that reads one byte: a pose whose centre lies off the grid or in a cell of cost >= 250
+// is in collision whatever its heading (src/collisiondetection.cpp:189-203).  pose_free() below comes to the same
+// verdict for such a pose; callers that only need to know whether ANY pose of a set collides ask this first.
+HD bool centre_blocked(const DevMap &m, float x, float y)
+{
+    uint32_t sx = 0, sy = 0;
+    if (!world_to_map(m, x, y, sx, sy))
+        return true;
+    return m.charmap[sx + sy * m.w] >= 250;
+}
+
 // src/collisiondetection.cpp:189-214 + :573-606.  true = free.
 template <class QuadSrc>
 HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float t)

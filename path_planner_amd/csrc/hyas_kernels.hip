@@ -1373,6 +1373,44 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     const float sharpest = 1 / m.shot_rho; // src/hybrid_a_star.cpp:496
     bool collided = false;
     unsigned long long tested = 0;
+    // sample k of the curve, as the reference's loop produces it
+    auto sample_at = [&](uint32_t k, float &x, float &y, float &t, bool &sharp) {
+        if (RS)
+        {
+            double s[3];
+            rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
+            x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
+        }
+        else if (BZ)
+        {
+            // src/hybrid_a_star.cpp:481-483: value, curvature and heading at x / length
+            const bz::Powers pw = bz::powers(m.seg_bz[k] / s_bezier_len);
+            float angle, curvature;
+            bz::value(s_bezier, pw, x, y);
+            bz::angle_curvature(s_bezier, pw, angle, curvature);
+            t = rad_0_2pi(angle);
+            sharp = !(curvature <= sharpest);
+        }
+        else
+        {
+            float q[3] = {0, 0, 0};
+            (void)db::sample(dpath, m.seg_db[k], q);
+            x = q[0], y = q[1], t = rad_0_2pi(q[2]);
+        }
+    };
+    // The shot fails when ANY of its samples collides (src/hybrid_a_star.cpp:441-447, :409-415, :500-510), and a
+    // sample whose centre cell is occupied collides: a curve longer than one batch first looks at SHOT_THREADS
+    // samples spread evenly over its whole length, one cost byte each.  Most shots through an obstacle end here,
+    // before a single polygon is tested.  (The counting kernel keeps to the serial order its figures are defined by.)
+    if (!STATS && nsamp > SHOT_BATCH)
+    {
+        const uint32_t k = (uint32_t)(((unsigned long long)tid * nsamp) / SHOT_THREADS);
+        float x = 0, y = 0, t = 0;
+        bool sharp = false;
+        sample_at(k, x, y, t, sharp);
+        if (__syncthreads_or((centre_blocked(m, x, y) || (BZ && sharp)) ? 1 : 0))
+            collided = true;
+    }
     for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_BATCH)
     {
         if (base)
@@ -1381,34 +1419,15 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             if (tid == 0)
                 s_xyt[0][0] = s_xyt[SHOT_BATCH][0], s_xyt[0][1] = s_xyt[SHOT_BATCH][1];
         }
+        bool blocked = false;
         {
             const uint32_t k = base + tid;
             float x = 0, y = 0, t = 0;
             bool sharp = false;
             if (tid < SHOT_BATCH && k < nsamp)
             {
-                if (RS)
-                {
-                    double s[3];
-                    rs::interpolate_prefix(q0, path, s_prefix, seg_tab[k] / rho, rho, s);
-                    x = (float)s[0], y = (float)s[1], t = rad_0_2pi((float)s[2]);
-                }
-                else if (BZ)
-                {
-                    // src/hybrid_a_star.cpp:481-483: value, curvature and heading at x / length
-                    const bz::Powers pw = bz::powers(m.seg_bz[k] / s_bezier_len);
-                    float angle, curvature;
-                    bz::value(s_bezier, pw, x, y);
-                    bz::angle_curvature(s_bezier, pw, angle, curvature);
-                    t = rad_0_2pi(angle);
-                    sharp = !(curvature <= sharpest);
-                }
-                else
-                {
-                    float q[3] = {0, 0, 0};
-                    (void)db::sample(dpath, m.seg_db[k], q);
-                    x = q[0], y = q[1], t = rad_0_2pi(q[2]);
-                }
+                sample_at(k, x, y, t, sharp);
+                blocked = !STATS && (centre_blocked(m, x, y) || (BZ && sharp));
             }
             if (base)
                 __syncthreads(); // slot 0 has been refreshed before slot SHOT_BATCH is overwritten
@@ -1417,7 +1436,14 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             if (BZ && tid < SHOT_BATCH)
                 s_sharp[tid] = sharp ? 1 : 0;
         }
-        __syncthreads();
+        // the batch's own cost bytes first (the barrier that publishes the samples carries the answer)
+        if (__syncthreads_or(blocked ? 1 : 0))
+        {
+            collided = true;
+            if (CLOCKS)
+                ++n_batches;
+            break;
+        }
         if (CLOCKS)
         {
             c2 = clock64();
