@@ -473,8 +473,10 @@ HD bool centre_blocked(const DevMap &m, float x, float y)
 }
 
 // src/collisiondetection.cpp:189-214 + :573-606.  true = free.
+// (sub, nsub): this caller walks entries sub, sub + nsub, ... of the obstacle list only; the pose is free iff all nsub
+// callers that share it say so (the verdict is an AND over the list's polygons).
 template <class QuadSrc>
-HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float t)
+HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float t, uint32_t sub = 0, uint32_t nsub = 1)
 {
     // Everything that decides which memory is read comes first, then the cost cell and the list bounds are
     // requested together (two trips to memory in a row instead of three); the verdict logic follows in the
@@ -504,7 +506,7 @@ HD bool pose_free(const DevMap &m, const QuadSrc &quads, float x, float y, float
         return true; // key absent from in_range_obstacle_map_: nothing to test
     typename QuadSrc::Cursor cur(idx, begin);
 #pragma unroll 1
-    for (uint32_t k = begin; k < e; ++k)
+    for (uint32_t k = begin + sub; k < e; k += nsub)
     {
         if (quads.stop())
             return true; // the caller no longer needs this verdict
@@ -632,9 +634,9 @@ HD bool seg_hits_quad(float r, double half_wid, F2 s, F2 e, const Quad &q)
     return seg_hits_verts_near(r, half_wid, s, e, qv(q, 0), qv(q, 1), qv(q, 2), qv(q, 3));
 }
 
-// src/collisiondetection.cpp:608-656.  true = free.
+// src/collisiondetection.cpp:608-656.  true = free.  (sub, nsub) as for pose_free().
 template <class QuadSrc>
-HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, float ex, float ey)
+HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, float ex, float ey, uint32_t sub = 0, uint32_t nsub = 1)
 {
     if (!on_grid(m, sx, sy) || !on_grid(m, ex, ey))
         return false;
@@ -662,7 +664,7 @@ HD bool segment_free(const DevMap &m, const QuadSrc &quads, float sx, float sy, 
             continue;
         typename QuadSrc::Cursor cur(idx, begin);
 #pragma unroll 1
-        for (uint32_t k = begin; k < end; ++k)
+        for (uint32_t k = begin + sub; k < end; k += nsub)
         {
             if (quads.stop())
                 return true; // the caller no longer needs this verdict

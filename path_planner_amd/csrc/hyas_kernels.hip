@@ -963,10 +963,15 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
 // With ADAPT == 1 a node has up to HYAS_AD_MAX_PAIRS + 1 candidates: sixteen lanes per node and test, eight nodes per
 // workgroup; the first lane of a node forms the node's {step, steering} list in workgroup memory, then the lanes take
 // one pair each.  count = 0xFF marks a node whose list did not fit.
+// With the fixed motion set four lanes share each candidate's test: a wave lasts as long as the longest obstacle list
+// among its lanes, and the lists are walked entry by entry, so each of the four takes every fourth entry (the verdict
+// is an AND over the list).  Without list walks the successor kernel takes 19 us, with them 29-37 us undivided.
 template <int ADAPT>
 struct ExpandShape
 {
-    static constexpr int LANES = ADAPT == 1 ? 16 : 8;               // lanes per node and kind of test
+    static constexpr int CAND = ADAPT == 1 ? 16 : 8;                // candidate slots per node
+    static constexpr int SUB = ADAPT == 0 ? 4 : 1;                  // lanes that share one candidate's list walk
+    static constexpr int LANES = CAND * SUB;                        // lanes per node and kind of test
     static constexpr int NODES = EXPAND_THREADS / 2 / LANES;        // nodes per workgroup
 };
 
@@ -976,7 +981,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
                                             unsigned long long *stats, Quad *s_quads, uint32_t block, StepIn *__restrict__ child = nullptr,
                                             uint32_t flags = 0)
 {
-    constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES;
+    constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES, CAND = ExpandShape<ADAPT>::CAND, SUB = ExpandShape<ADAPT>::SUB;
     const int tid = threadIdx.x;
     const StepQuads sq = stage_quads(m, s_quads, tid);
     __shared__ uint8_t s_pose[EXPAND_THREADS / 2];
@@ -984,7 +989,8 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     __shared__ int s_pairs[ADAPT == 1 ? NODES : 1]; // pairs of the node, -1: too many
     // LANES lanes per node and test; waves 0-1 run the pose tests, waves 2-3 the swept-segment tests
     // (a wave that mixed the two would run them one after the other)
-    const int lane = tid & 63, sl = tid & (LANES - 1), local = (tid & (EXPAND_THREADS / 2 - 1)) / LANES;
+    // a node's lanes: candidate sl, part `part` of its list walk (part 0 lanes of a node lie side by side)
+    const int lane = tid & 63, sl = tid & (CAND - 1), part = (tid & (LANES - 1)) / CAND, local = (tid & (EXPAND_THREADS / 2 - 1)) / LANES;
     const uint32_t slot = block * NODES + local;
     const bool in_launch = slot < n;
     const StepIn node = in[in_launch ? slot : 0];
@@ -1080,15 +1086,21 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         {
             evaluated = true;
             if (pose_lane)
-                part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st);
+                part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st, (uint32_t)part, (uint32_t)SUB);
             else
-                part_ok = segment_free(m, sq, sx, sy, node.x, node.y);
+                part_ok = segment_free(m, sq, sx, sy, node.x, node.y, (uint32_t)part, (uint32_t)SUB);
         }
+    }
+    if (SUB > 1) // a candidate is free iff every part of its list says so
+    {
+#pragma unroll
+        for (int o = CAND; o < LANES; o <<= 1)
+            part_ok = (__shfl_xor(part_ok ? 1 : 0, o, 64) != 0) && part_ok;
     }
     if (pose_lane)
         s_pose[tid] = part_ok ? 1 : 0;
     __syncthreads();
-    const bool ok = seg_lane && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0;
+    const bool ok = seg_lane && part == 0 && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0;
     hyas_succ s;
     if (ok)
     {
@@ -1103,8 +1115,8 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         s.pad = (flags & ROUND_TAG_CANDIDATE) ? (uint16_t)((sl + 1) << 8) : (uint16_t)0;
     }
     // compact in candidate order, as the reference's output vector
-    const unsigned grp = (lane / LANES) * LANES;
-    constexpr unsigned long long GROUP = (1ull << LANES) - 1ull;
+    const unsigned grp = (lane / LANES) * LANES; // the node's part 0 lanes: grp .. grp + CAND - 1
+    constexpr unsigned long long GROUP = (1ull << CAND) - 1ull;
     const unsigned mask = (unsigned)((__ballot(ok) >> grp) & GROUP);
     const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & GROUP);
     if (child)
@@ -1116,7 +1128,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         if (!(bf == bf))
             bf = INFINITY;
         int bi = ok ? sl : 255;
-        for (int off = LANES / 2; off > 0; off >>= 1)
+        for (int off = CAND / 2; off > 0; off >>= 1)
         {
             const float of = __shfl_xor(bf, off, 64);
             const int oi = __shfl_xor(bi, off, 64);
@@ -1128,7 +1140,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
             s.pad |= 1;
             child[slot] = StepIn{s.x, s.y, s.t, s.g, prim, node.query, flags & ROUND_CHILD_SHOOT, node.pad};
         }
-        if (in_launch && seg_lane && sl == 0 && bi == 255) // nothing to expand one level down
+        if (in_launch && seg_lane && sl == 0 && part == 0 && bi == 255) // nothing to expand one level down
             child[slot] = StepIn{node.x, node.y, node.t, node.g, node.prim, node.query, STEP_DEAD, node.pad};
     }
     if (ok)
@@ -1136,13 +1148,13 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         int pos = __popc(mask & ((1u << sl) - 1u));
         succ[(size_t)slot * m.n_slots + pos] = s;
     }
-    const bool writer = in_launch && seg_lane && sl == 0;
+    const bool writer = in_launch && seg_lane && sl == 0 && part == 0;
     if (writer) // low nibble: emitted successors, high nibble: candidates that got a verdict
         count[slot] = overflow ? (uint8_t)0xFF : (uint8_t)(__popc(mask) | (__popc(emask) << 4));
     if (MODE == 1)
     {
-        uint32_t walked = (seg_lane && evaluated) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
-        for (int off = LANES / 2; off > 0; off >>= 1)
+        uint32_t walked = (seg_lane && evaluated && part == 0) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
+        for (int off = CAND / 2; off > 0; off >>= 1)
             walked += __shfl_xor(walked, off, 64);
         if (writer)
         {
@@ -1398,20 +1410,82 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
             x = q[0], y = q[1], t = rad_0_2pi(q[2]);
         }
     };
-    // The shot fails when ANY of its samples collides (src/hybrid_a_star.cpp:441-447, :409-415, :500-510), and a
-    // sample whose centre cell is occupied collides: a curve longer than one batch first looks at SHOT_THREADS
-    // samples spread evenly over its whole length, one cost byte each.  Most shots through an obstacle end here,
-    // before a single polygon is tested.  (The counting kernel keeps to the serial order its figures are defined by.)
-    if (!STATS && nsamp > SHOT_BATCH)
+    // The shot fails when ANY of its samples collides (src/hybrid_a_star.cpp:441-447, :409-415, :500-510), so the
+    // order in which they are looked at is free, and a sample whose centre cell is occupied collides: every batch first
+    // reads one cost byte per sample.  Most shots through an obstacle end there, before a single polygon is tested.
+    // (The counting kernel keeps to the serial order its figures are defined by.)
+    // Curves longer than one batch: batch b takes samples b, b + nb, b + 2 nb, ... (nb batches), so that every batch
+    // covers the whole curve.  A collision is a stretch of the curve, not a single sample, so the first batch nearly
+    // always meets it, mostly with its cost bytes alone; taken in order, a curve that is free for its first 25 m
+    // would run the exact tests of a whole batch for nothing.  A sample's predecessor is the lane's own sample of the
+    // batch before; the first batch forms its predecessors itself.
+    const bool strided = !STATS && nsamp > SHOT_BATCH; // uniform
+    if (strided && !collided)
     {
-        const uint32_t k = (uint32_t)(((unsigned long long)tid * nsamp) / SHOT_THREADS);
-        float x = 0, y = 0, t = 0;
-        bool sharp = false;
-        sample_at(k, x, y, t, sharp);
-        if (__syncthreads_or((centre_blocked(m, x, y) || (BZ && sharp)) ? 1 : 0))
-            collided = true;
+        __shared__ float s_pxy[SHOT_BATCH][2];
+        const uint32_t nb = (nsamp + SHOT_BATCH - 1) / SHOT_BATCH;
+        const bool sampler = tid < SHOT_BATCH;
+        float prev_x = 0, prev_y = 0;
+        for (uint32_t b = 0; b < nb && !collided; ++b)
+        {
+            const uint32_t k = (uint32_t)tid * nb + b;
+            float x = 0, y = 0, t = 0;
+            bool sharp = false, blocked = false;
+            if (sampler && k < nsamp)
+            {
+                sample_at(k, x, y, t, sharp);
+                blocked = centre_blocked(m, x, y) || (BZ && sharp);
+            }
+            if (sampler)
+            {
+                s_xyt[tid + 1][0] = x, s_xyt[tid + 1][1] = y, s_xyt[tid + 1][2] = t;
+                s_pxy[tid][0] = prev_x, s_pxy[tid][1] = prev_y;
+                if (BZ)
+                    s_sharp[tid] = sharp ? 1 : 0;
+            }
+            if (__syncthreads_or(blocked ? 1 : 0))
+            {
+                collided = true;
+                break;
+            }
+            if (CLOCKS)
+                ++n_batches;
+            if (b == 0)
+            {
+                float qx = node.x, qy = node.y, qt = 0;
+                bool qs = false;
+                if (sampler && k >= 1 && k < nsamp)
+                    sample_at(k - 1, qx, qy, qt, qs);
+                if (sampler)
+                    s_pxy[tid][0] = qx, s_pxy[tid][1] = qy;
+                __syncthreads();
+            }
+            for (int half = 0; half < SHOT_BATCH / (SHOT_THREADS / 2); ++half)
+            {
+                const uint32_t j = half * (SHOT_THREADS / 2) + (tid & (SHOT_THREADS / 2 - 1)); // sample inside the batch
+                const uint32_t kk = j * nb + b;
+                const bool pose_lane = (tid < SHOT_THREADS / 2) != ((half & 1) != 0);
+                if ((uint32_t)(half * (SHOT_THREADS / 2)) * nb + b >= nsamp)
+                    break;
+                bool hit = false;
+                const float jx = s_xyt[j + 1][0], jy = s_xyt[j + 1][1], jt = s_xyt[j + 1][2];
+                const float px = s_pxy[j][0], py = s_pxy[j][1];
+                if (kk < nsamp && s_hit == 0)
+                {
+                    if (pose_lane)
+                        hit = !(on_grid(m, jx, jy) && pose_free(m, sq, jx, jy, jt)) || (BZ && s_sharp[j] != 0);
+                    else
+                        hit = !segment_free(m, sq, jx, jy, px, py);
+                }
+                if (hit)
+                    s_hit = 1;
+            }
+            __syncthreads();
+            collided = s_hit != 0;
+            prev_x = x, prev_y = y;
+        }
     }
-    for (uint32_t base = 0; base < nsamp && !collided; base += SHOT_BATCH)
+    for (uint32_t base = 0; base < nsamp && !collided && !strided; base += SHOT_BATCH)
     {
         if (base)
         {
