@@ -293,7 +293,11 @@ def main():
                             "construction; a launch lasts as long as its slowest workgroup's dependent chain (solve, pick, "
                             "interpolate, list walk), stretched by the launches that share the SIMDs. Bytes count every node a "
                             "launch processed, including nodes expanded ahead of time (counters.nodes); `value` and useful_frac "
-                            "count only what the search consumed (counters.nodes_consumed_by_the_search)"}
+                            "count only what the search consumed (counters.nodes_consumed_by_the_search). The bytes are those "
+                            "of the reference's serial scan (every shot sample up to the first colliding one with its obstacle "
+                            "lists); the kernel decides most shots from one cost byte per sample and reads far fewer list "
+                            "entries (compare `traffic` and roofline.l2), so `achieved` is a rate of algorithmic work, not "
+                            "of bytes moved"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(map_arr, starts, goals)
             cpu_all = cpu_baseline_all_cores(map_arr, starts, goals)
