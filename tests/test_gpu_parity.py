@@ -273,6 +273,21 @@ def test_shot(parking, maze):
         assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
 
 
+def test_shot_long_curves(oracle_built):
+    """Shots over tens of metres on the 180 x 60 map: curves of several hundred to well over a thousand samples, which
+    the kernel tests in passes that each cover the whole curve, accepted and rejected ones, for all three curve types
+    (verdict and length bit for bit)."""
+    for curve, kw in ((1, {}), (0, {}), (2, {})):
+        p = Pair("map_large", position_resolution=1, max_iterations=10, curve_type=curve, **kw)
+        nodes, goals = _nodes(p, 600, 81 + curve)
+        a, la = p.o.shot(nodes, goals)
+        b, lb = p.h.shot(nodes, goals)
+        long_ones = la > 25.6 * 2  # more than two passes of 256 samples 0.1 m apart (Dubins: 0.2 m)
+        assert long_ones.sum() > 100 and a[long_ones].sum() > 5 and (a[long_ones] == 0).sum() > 50
+        assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+
+
 def _plan_compare(p, starts, goals):
     res = p.h.plan_batch(starts, goals)
     for i in range(len(starts)):
