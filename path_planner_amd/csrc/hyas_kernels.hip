@@ -963,14 +963,15 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
 // With ADAPT == 1 a node has up to HYAS_AD_MAX_PAIRS + 1 candidates: sixteen lanes per node and test, eight nodes per
 // workgroup; the first lane of a node forms the node's {step, steering} list in workgroup memory, then the lanes take
 // one pair each.  count = 0xFF marks a node whose list did not fit.
-// With the fixed motion set four lanes share each candidate's test: a wave lasts as long as the longest obstacle list
-// among its lanes, and the lists are walked entry by entry, so each of the four takes every fourth entry (the verdict
-// is an AND over the list).  Without list walks the successor kernel takes 19 us, with them 29-37 us undivided.
+// Four lanes (two where a node has sixteen candidate slots) share each candidate's test: a wave lasts as long as the
+// longest obstacle list among its lanes, and the lists are walked entry by entry, so each of the lanes takes every
+// fourth (second) entry (the verdict is an AND over the list).  Without list walks the successor kernel takes 19 us,
+// with them 29-37 us undivided (fixed motion set); the adaptive modes' steps of several metres read the unpruned lists.
 template <int ADAPT>
 struct ExpandShape
 {
     static constexpr int CAND = ADAPT == 1 ? 16 : 8;                // candidate slots per node
-    static constexpr int SUB = ADAPT == 0 ? 4 : 1;                  // lanes that share one candidate's list walk
+    static constexpr int SUB = ADAPT == 1 ? 2 : 4;                  // lanes that share one candidate's list walk
     static constexpr int LANES = CAND * SUB;                        // lanes per node and kind of test
     static constexpr int NODES = EXPAND_THREADS / 2 / LANES;        // nodes per workgroup
 };
@@ -991,6 +992,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     // (a wave that mixed the two would run them one after the other)
     // a node's lanes: candidate sl, part `part` of its list walk (part 0 lanes of a node lie side by side)
     const int lane = tid & 63, sl = tid & (CAND - 1), part = (tid & (LANES - 1)) / CAND, local = (tid & (EXPAND_THREADS / 2 - 1)) / LANES;
+    const int nl = tid & (LANES - 1); // lane within the node's lanes of this kind
     const uint32_t slot = block * NODES + local;
     const bool in_launch = slot < n;
     const StepIn node = in[in_launch ? slot : 0];
@@ -1010,7 +1012,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     {
         cell = ad::cell_of(m, node.x, node.y);
         if (pose_lane && cell.n <= (uint32_t)AD_LDS_RANGES)
-            for (uint32_t i = (uint32_t)sl; i < cell.n; i += LANES)
+            for (uint32_t i = (uint32_t)nl; i < cell.n; i += LANES)
                 s_rng[local][i] = cell.rng[i];
     }
     if (ADAPT != 0)
@@ -1026,13 +1028,13 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         // takes range i -- its ends in normal form, then its candidates -- and the first lane only applies the
         // duplicate rule to what the others found, in range order.  (Not for the configurations and cells named
         // at ad::emit_range: the first lane then forms the list by itself.)
-        static_assert(LANES >= AD_LDS_RANGES, "one lane per staged range");
+        static_assert(CAND >= AD_LDS_RANGES, "one lane per staged range");
         __shared__ ad::RangePre s_pre[NODES][AD_LDS_RANGES];
         __shared__ float s_estep[NODES][AD_LDS_RANGES * HYAS_AD_EMIT_MAX], s_esteer[NODES][AD_LDS_RANGES * HYAS_AD_EMIT_MAX];
         __shared__ int s_ecount[NODES][AD_LDS_RANGES];
         const bool shared_out = live && ad::staged_selection_applies(m) && cell.n <= (uint32_t)AD_LDS_RANGES &&
                                 !(cell.density > m.ad_constant_density);
-        const bool my_range = shared_out && pose_lane && (uint32_t)sl < cell.n;
+        const bool my_range = shared_out && pose_lane && part == 0 && (uint32_t)sl < cell.n;
         if (my_range)
             s_pre[local][sl] = ad::range_pre(cell.rng[sl]);
         __syncthreads();
@@ -1043,7 +1045,7 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
                                                  &s_estep[local][sl * HYAS_AD_EMIT_MAX], &s_esteer[local][sl * HYAS_AD_EMIT_MAX]);
         }
         __syncthreads();
-        if (live && pose_lane && sl == 0)
+        if (live && pose_lane && sl == 0 && part == 0)
         {
             ad::Pairs p;
             p.step = s_step[local], p.steer = s_steer[local];
@@ -2230,7 +2232,7 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
 {
     if (!n)
         return;
-    const uint32_t nodes = m.ad_mode == 1 ? ExpandShape<1>::NODES : ExpandShape<0>::NODES;
+    const uint32_t nodes = m.ad_mode == 1 ? ExpandShape<1>::NODES : m.ad_mode == 2 ? ExpandShape<2>::NODES : ExpandShape<0>::NODES;
     const dim3 grid((n + nodes - 1) / nodes);
     if (m.ad_mode == 1) // the adaptive variants keep no work counters
         hipLaunchKernelGGL((k_expand<0, 1>), grid, dim3(EXPAND_THREADS), 0, s, m, in, n, goals, twod, count, succ, stats);
