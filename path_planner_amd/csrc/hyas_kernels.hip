@@ -963,15 +963,17 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
 // With ADAPT == 1 a node has up to HYAS_AD_MAX_PAIRS + 1 candidates: sixteen lanes per node and test, eight nodes per
 // workgroup; the first lane of a node forms the node's {step, steering} list in workgroup memory, then the lanes take
 // one pair each.  count = 0xFF marks a node whose list did not fit.
-// Four lanes (two where a node has sixteen candidate slots) share each candidate's test: a wave lasts as long as the
-// longest obstacle list among its lanes, and the lists are walked entry by entry, so each of the lanes takes every
-// fourth (second) entry (the verdict is an AND over the list).  Without list walks the successor kernel takes 19 us,
-// with them 29-37 us undivided (fixed motion set); the adaptive modes' steps of several metres read the unpruned lists.
+// Four lanes (eight with adaptive step size) share each candidate's test: a wave lasts as long as the longest obstacle
+// list among its lanes, and the lists are walked entry by entry, so each of the lanes takes every fourth (eighth)
+// entry (the verdict is an AND over the list).  Without list walks the successor kernel takes 19 us, with them
+// 29-37 us undivided (fixed motion set; eight lanes gain nothing over four there); the adaptive modes' steps of
+// several metres read the unpruned lists of two cells (round kernel 70 -> 53 us and 59 -> 39 us).  A node's lanes of
+// one kind stay within a wave.
 template <int ADAPT>
 struct ExpandShape
 {
     static constexpr int CAND = ADAPT == 1 ? 16 : 8;                // candidate slots per node
-    static constexpr int SUB = ADAPT == 1 ? 2 : 4;                  // lanes that share one candidate's list walk
+    static constexpr int SUB = ADAPT == 2 ? 8 : 4;                  // lanes that share one candidate's list walk
     static constexpr int LANES = CAND * SUB;                        // lanes per node and kind of test
     static constexpr int NODES = EXPAND_THREADS / 2 / LANES;        // nodes per workgroup
 };
