@@ -71,6 +71,9 @@ struct hyas_ctx
     void *h_scratch = nullptr;
     size_t h_scratch_bytes = 0;
     float *d_twod = nullptr;
+    // successor filter of the search rounds: per query of a chunk and per cell the cost a successor has to beat (hyas::CellFilter)
+    int32_t *d_bound = nullptr;
+    size_t d_bound_bytes = 0;
     // popped nodes of the search rounds: device memory the host stores into directly (large BAR), null if unavailable
     void *d_nodes = nullptr;
     size_t d_nodes_bytes = 0;

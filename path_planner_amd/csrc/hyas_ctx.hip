@@ -729,6 +729,8 @@ void hyas_destroy(hyas_ctx *c)
         (void)hipFree(c->d_twod);
     if (c->d_nodes)
         (void)hipFree(c->d_nodes);
+    if (c->d_bound)
+        (void)hipFree(c->d_bound);
     if (c->d_stats)
         (void)hipFree(c->d_stats);
     if (c->ev0)

@@ -21,6 +21,27 @@ struct StepIn
 #define ROUND_CHILD_SHOOT 1u   // the records written for a deeper launch ask for the analytic shot
 #define ROUND_TAG_CANDIDATE 2u // hyas_succ::pad, high byte: 1 + index of the motion-set entry (fixed motion set) the successor comes from
 
+// Successors the search would drop anyway (src/hybrid_a_star.cpp:264, :271: cell closed, or cell open with a cost that the
+// new one does not beat) are dropped by the round kernel before a record is written.  bound[query * cells + idx] holds,
+// as the bits of a float, an UPPER bound of the cost a successor in that cell has to beat: +inf while the cell is
+// unseen, the cell's cost while it is open, -inf once it is closed.  The true value only ever falls, every value the
+// host sends was true at some time, and the kernel keeps the minimum of what it was sent, so the bound never lies below
+// the true value and a test against it drops no successor the host would keep; what it lets through the host tests again.
+struct CellUpd
+{
+    uint32_t query; // row of `bound`
+    int32_t idx;    // Node3D::setIdx of the cell
+    int32_t bits;   // new value: bits of the pushed node's cost, or of -inf when the cell was closed
+    uint32_t pad;
+};
+struct CellFilter
+{
+    int32_t *bound;      // null: no filter
+    uint32_t cells;      // entries per query
+    const CellUpd *upd;  // changes since the last launch, applied by extra workgroups of this one
+    uint32_t n_upd;
+};
+
 void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
 // map ingest: occupancy values, occupancy bit tiles (padded may be null), per-key in-range lists.
 void launch_occupancy(const uint8_t *cost, size_t n, int8_t *occ, hipStream_t s);
@@ -47,7 +68,7 @@ void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal 
 hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode);
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                  int stats_mode, hipStream_t s, StepIn *child = nullptr, bool child_shoot = false);
+                  int stats_mode, hipStream_t s, StepIn *child = nullptr, bool child_shoot = false, CellFilter filter = CellFilter{nullptr, 0, nullptr, 0});
 // child (optional, n records in device memory): the launch also writes, for every node, the input record of its
 // lowest-f successor (shoot = child_shoot; STEP_DEAD when the node has none), ready to be the `in` of a further launch
 // on the same stream, and marks that successor's record with bit 0 of pad.  A search round tags every successor

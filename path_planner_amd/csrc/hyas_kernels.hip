@@ -982,7 +982,7 @@ template <int MODE, int ADAPT>
 __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__restrict__ in, uint32_t n, const hyas_goal *__restrict__ goals,
                                             const float *__restrict__ twod, uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
                                             unsigned long long *stats, Quad *s_quads, uint32_t block, StepIn *__restrict__ child = nullptr,
-                                            uint32_t flags = 0)
+                                            uint32_t flags = 0, const int32_t *__restrict__ bound = nullptr, uint32_t bound_cells = 0)
 {
     constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES, CAND = ExpandShape<ADAPT>::CAND, SUB = ExpandShape<ADAPT>::SUB;
     const int tid = threadIdx.x;
@@ -1062,6 +1062,8 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     bool part_ok = false, evaluated = false, overflow = false;
     float sx = 0, sy = 0, st = 0;
     int prim = 0;
+    float s_g = 0, beat = INFINITY; // the successor's cost, and what it has to beat to be of use to the search
+    int s_idx = 0;
     if (live)
     {
         // this lane's candidate: {step, steering angle}
@@ -1089,6 +1091,15 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
         if (have && successor_from_pair(node.x, node.y, node.t, first, steer, sx, sy, st, prim))
         {
             evaluated = true;
+            if (seg_lane && part == 0)
+            {
+                // cost and cell of the lane that writes the record; the cell's bound is requested here and used
+                // after the list walks
+                s_g = cost_so_far(m, node.g, normf(sub(f2(sx, sy), f2(node.x, node.y))), prim, node.prim);
+                s_idx = idx_3d(m, sx, sy, st);
+                if (bound && s_idx >= 0 && (uint32_t)s_idx < bound_cells)
+                    beat = __int_as_float(__builtin_nontemporal_load(bound + (size_t)node.query * bound_cells + (uint32_t)s_idx));
+            }
             if (pose_lane)
                 part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st, (uint32_t)part, (uint32_t)SUB);
             else
@@ -1104,15 +1115,15 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     if (pose_lane)
         s_pose[tid] = part_ok ? 1 : 0;
     __syncthreads();
-    const bool ok = seg_lane && part == 0 && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0;
+    // (s_g >= beat is false for a NaN cost: such a successor is left to the host)
+    const bool ok = seg_lane && part == 0 && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0 && !(s_g >= beat);
     hyas_succ s;
     if (ok)
     {
-        float step = normf(sub(f2(sx, sy), f2(node.x, node.y)));
         s.x = sx, s.y = sy, s.t = st;
-        s.g = cost_so_far(m, node.g, step, prim, node.prim);
+        s.g = s_g;
         s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
-        s.idx = idx_3d(m, sx, sy, st);
+        s.idx = s_idx;
         s.prim = (int8_t)prim;
         s.free = 1;
         // search rounds: which entry of the motion set this successor comes from (1-based, high byte)
@@ -1652,23 +1663,39 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_shot(DevMap m
         shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
 }
 
-// One search round in one launch: workgroups [0, n) evaluate the analytic shot
-// of node i, the following ceil(n / 16) workgroups the successors of 16 nodes
-// each.  The two parts are independent; the shot workgroups come first because
-// they run longest.
+// One search round in one launch: the first ceil(n_upd / ROUND_THREADS) workgroups bring the cell bounds of the
+// successor filter up to date (CellFilter), workgroups [0, n) behind them evaluate the analytic shot
+// of node i, the following ceil(n / NODES) workgroups the successors of NODES nodes
+// each.  The parts are independent (a bound that arrives late only lets a successor through that the host then drops);
+// the shot workgroups come before the successor workgroups because they run longest.
 template <int MODE, int CURVE, int ADAPT>
 __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap m, const StepIn *__restrict__ in, uint32_t n,
                                                                         const hyas_goal *__restrict__ goals, const float *__restrict__ twod,
                                                                         const double *__restrict__ seg_tab, uint32_t seg_cap,
                                                                         uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
                                                                         uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
-                                                                        unsigned long long *stats, StepIn *__restrict__ child, uint32_t flags)
+                                                                        unsigned long long *stats, StepIn *__restrict__ child, uint32_t flags,
+                                                                        CellFilter filter)
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
-    if (blockIdx.x < n) // uniform across the workgroup
-        shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, blockIdx.x);
+    const uint32_t n_upd_blocks = (filter.n_upd + ROUND_THREADS - 1) / ROUND_THREADS;
+    if (blockIdx.x < n_upd_blocks) // uniform across the workgroup
+    {
+        const uint32_t i = blockIdx.x * ROUND_THREADS + threadIdx.x;
+        if (i < filter.n_upd)
+        {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 u = reinterpret_cast<const u32x4 *>(filter.upd)[i];
+            if (u.y < filter.cells) // signed order of the bits = order of the floats for costs >= 0, and -inf lies below them all
+                atomicMin(filter.bound + (size_t)u.x * filter.cells + u.y, (int32_t)u.z);
+        }
+        return;
+    }
+    const uint32_t block = blockIdx.x - n_upd_blocks;
+    if (block < n)
+        shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, block);
     else
-        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, blockIdx.x - n, child, flags);
+        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, block - n, child, flags, filter.bound, filter.cells);
 }
 
 // The accepted curves of n queries, one workgroup each: samples {x, y, t} of
@@ -2282,25 +2309,25 @@ struct LaunchRound
     template <int ADAPT>
     static void with(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
                      uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, StepIn *child,
-                     uint32_t child_shoot, hipStream_t s)
+                     uint32_t child_shoot, CellFilter filter, hipStream_t s)
     {
         constexpr uint32_t nodes = ExpandShape<ADAPT>::NODES;
-        const dim3 grid(n + (n + nodes - 1) / nodes);
+        const dim3 grid((filter.n_upd + ROUND_THREADS - 1) / ROUND_THREADS + n + (n + nodes - 1) / nodes);
         hipLaunchKernelGGL((k_round<MODE, CURVE, ADAPT>), grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
-                           count, succ, stats, child, child_shoot);
+                           count, succ, stats, child, child_shoot, filter);
     }
     static void go(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
                    uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, StepIn *child, uint32_t child_shoot,
-                   hipStream_t s)
+                   CellFilter filter, hipStream_t s)
     {
         if constexpr (MODE == 0) // the adaptive variants exist without counters only
         {
             if (m.ad_mode == 1)
-                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, s);
+                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, s);
             if (m.ad_mode == 2)
-                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, s);
+                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, s);
         }
-        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, s);
+        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, s);
     }
 };
 
@@ -2349,15 +2376,17 @@ void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal 
 
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                  int stats_mode, hipStream_t s, StepIn *child, bool child_shoot)
+                  int stats_mode, hipStream_t s, StepIn *child, bool child_shoot, CellFilter filter)
 {
     if (!n)
         return;
     int mode = (stats && stats_mode >= 1 && stats_mode <= 2) ? stats_mode : 0;
     if (m.ad_mode != 0)
         mode = 0;
+    if (!filter.bound)
+        filter = CellFilter{nullptr, 0, nullptr, 0};
     dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child,
-                                     (child_shoot ? ROUND_CHILD_SHOOT : 0u) | ROUND_TAG_CANDIDATE, s);
+                                     (child_shoot ? ROUND_CHILD_SHOOT : 0u) | ROUND_TAG_CANDIDATE, filter, s);
 }
 
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s)

@@ -110,6 +110,7 @@ struct CellMap
 
 struct Query
 {
+    uint32_t qi = 0; // index within the chunk: row of the goals, the 2D cost maps and the successor filter
     hyas_goal goal;
     SNode start;
     uint32_t dist_start_goal_bits = 0; // bits of the float GetDistance(start, goal), for the adaptive steering selection
@@ -147,13 +148,27 @@ struct Query
     std::vector<float> path;
 };
 
+// Changes of cell state a worker has seen this round, for the successor filter on the GPU (CellFilter, hyas_kernels.h).
+// The sink lives on the worker's stack and writes into a buffer of its own: nothing here shares a cache line with
+// another worker.  What does not fit is left out (a bound that stays too high only drops less).
+struct UpdSink
+{
+    CellUpd *p;
+    uint32_t n, cap;
+    void add(uint32_t query, int32_t idx, int32_t bits)
+    {
+        if (n < cap)
+            p[n++] = CellUpd{query, idx, bits, 0};
+    }
+};
+
 // HYAS_TRACE: where the host time of taking successors goes, per thread, flushed by the worker loop
 struct ConsumeProbe
 {
     uint64_t dup = 0, cell = 0, push = 0, chain = 0, heads = 0, succ = 0, pushed = 0;
+    uint64_t drop_closed = 0, drop_worse = 0, drop_tie = 0, drop_dup = 0; // successors dropped, by the test that dropped them
 };
 static thread_local ConsumeProbe t_probe;
-static bool g_probe_on = false;
 
 struct Driver
 {
@@ -161,7 +176,8 @@ struct Driver
     const DevMap &m;
     const hyas_params &P;
     float rad3; // ConvertDegToRad(3), src/hybrid_a_star.cpp:973
-    Driver(hyas_ctx *ctx) : c(ctx), m(ctx->dm), P(ctx->P), rad3(deg2rad(3)) {}
+    const bool probe_on; // HYAS_TRACE: the worker threads count cycles and drops into t_probe
+    Driver(hyas_ctx *ctx, bool probe) : c(ctx), m(ctx->dm), P(ctx->P), rad3(deg2rad(3)), probe_on(probe) {}
 
     // ---- duplicate check -------------------------------------------------
     // DuplicateCheck (:968-980) asks whether ANY open-list entry lies within
@@ -230,12 +246,12 @@ struct Driver
             for (int dx = xlo; dx <= xhi; ++dx)
             {
                 const size_t b = bucket_hash(bx + dx, by + dy, mask);
-                if (g_probe_on && q.dup_head[b] >= 0)
+                if (probe_on && q.dup_head[b] >= 0)
                     t_probe.heads += 1;
                 for (int32_t id = q.dup_head[b]; id >= 0; id = q.arena[id].dup_next)
                 {
                     const SNode &e = q.arena[id];
-                    if (g_probe_on)
+                    if (probe_on)
                         t_probe.chain += 1;
                     if ((double)hy_fabsf(e.x - x) < 0.05 && (double)hy_fabsf(e.y - y) < 0.05 && hy_fabsf(e.t - t) < rad3)
                         return true;
@@ -377,7 +393,9 @@ struct Driver
     // ---- one query, host side of one round --------------------------------
     // Pops until a node has to be expanded (:80-147).  Returns true when the
     // query wants a slot in this round's kernel launch.
-    bool advance(Query &q)
+    // upd (optional): changes of cell state for the successor filter on the GPU (CellFilter, hyas_kernels.h)
+    static constexpr int32_t CLOSED_BITS = (int32_t)0xFF800000u; // -inf
+    bool advance(Query &q, UpdSink *upd = nullptr)
     {
         while (!q.heap.empty())
         {
@@ -393,6 +411,8 @@ struct Driver
                 continue;
             }
             cell.closed = 1, cell.open = 0;
+            if (upd)
+                upd->add(q.qi, iPred, CLOSED_BITS);
             pop(q);
             if (q.iterations > P.max_iterations)
             {
@@ -444,7 +464,7 @@ struct Driver
         int32_t id[HYAS_MAX_NODES];
     };
     void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ, int32_t *best_child = nullptr,
-                 Wanted *wanted = nullptr)
+                 Wanted *wanted = nullptr, UpdSink *upd = nullptr)
     {
         const int32_t pid = q.cur;
         if (best_child)
@@ -487,28 +507,43 @@ struct Driver
         for (int k = 0; k < count; ++k)
         {
             const hyas_succ &s = succ[k];
-            const uint64_t p0 = g_probe_on ? __builtin_ia32_rdtsc() : 0;
+            const uint64_t p0 = probe_on ? __builtin_ia32_rdtsc() : 0;
             const int32_t iSucc = s.idx;
             CellMap::Slot *seen = q.cells.find(iSucc);
-            t_probe.succ += 1;
-            const uint64_t p1 = g_probe_on ? __builtin_ia32_rdtsc() : 0;
-            t_probe.cell += p1 - p0;
+            const uint64_t p1 = probe_on ? __builtin_ia32_rdtsc() : 0;
+            if (probe_on)
+                t_probe.succ += 1, t_probe.cell += p1 - p0;
             const float newG = s.g;
             if (seen && (seen->closed || (seen->open && !(newG < seen->g))))
+            {
+                if (probe_on)
+                    (seen->closed ? t_probe.drop_closed : t_probe.drop_worse) += 1;
                 continue;
+            }
             const bool same_cell = q.cur_idx == iSucc;
             if (same_cell && s.g + s.h > pred.g + pred.h + P.tie_breaker)
+            {
+                if (probe_on)
+                    t_probe.drop_tie += 1;
                 continue;
+            }
             const bool dup = dup_exists(q, s.x, s.y, s.t);
-            const uint64_t p2 = g_probe_on ? __builtin_ia32_rdtsc() : 0;
-            t_probe.dup += p2 - p1;
+            const uint64_t p2 = probe_on ? __builtin_ia32_rdtsc() : 0;
+            if (probe_on)
+                t_probe.dup += p2 - p1, t_probe.drop_dup += dup ? 1 : 0;
             if (dup)
                 continue;
             SNode n{s.x, s.y, s.t, s.g, s.h, (int16_t)s.prim, (int16_t)((int)(s.pad >> 8) - 1), same_cell ? pred.pred : pid, -1, -1};
             CellMap::Slot &cell = seen ? *seen : q.cells.get(iSucc);
             cell.g = n.g, cell.open = 1, cell.closed = 0;
             push(q, n, iSucc);
-            if (g_probe_on)
+            if (upd)
+            {
+                int32_t bits;
+                std::memcpy(&bits, &n.g, sizeof bits);
+                upd->add(q.qi, iSucc, bits);
+            }
+            if (probe_on)
                 t_probe.push += __builtin_ia32_rdtsc() - p2, t_probe.pushed += 1;
             if (k == kmin)
                 *best_child = (int32_t)q.arena.size() - 1;
@@ -748,7 +783,8 @@ static size_t gcap_hint(size_t cn, int ng) { return (cn + ng - 1) / ng; }
 int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out)
 {
     HYAS_HIP(c, hipSetDevice(c->device));
-    Driver D(c);
+    const bool trace_on = std::getenv("HYAS_TRACE") != nullptr;
+    Driver D(c, trace_on);
     const DevMap &m = c->dm;
     const int K = m.n_slots;
     reset_timers(c);
@@ -765,13 +801,19 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // Queries are processed in chunks: each query of a chunk owns a 2D cost map in device memory, so a chunk takes
     // at most a quarter of the free device memory (8192 queries at most; HYAS_CHUNK overrides).
     const size_t twod = c->twod_size;
+    // Successor filter on the GPU (CellFilter, hyas_kernels.h): one bound per query and cell (Node3D::setIdx: heading
+    // bins 0..headings, rows 0..h, columns 0..w), kept up to date by the pops and pushes of every round.  HYAS_FILTER=0
+    // turns it off; the answers are the same either way, the host then sees every traversable successor.
+    const bool filter_on = !(std::getenv("HYAS_FILTER") && std::atoi(std::getenv("HYAS_FILTER")) == 0);
+    const size_t cells3d = (size_t)(c->P.headings + 1) * m.w * m.h + m.w + 1;
     size_t chunk_cap = 8192;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
             (void)hipGetLastError(), free_b = (size_t)8 << 30;
-        const size_t per_query = 2 * twod * sizeof(float) + 4096; // two sets of cost maps when chunks are pipelined
-        const size_t reuse = c->d_twod_bytes; // already held by this context
+        // two sets of cost maps when chunks are pipelined, one row of cell bounds
+        const size_t per_query = 2 * twod * sizeof(float) + 4096 + (filter_on ? cells3d * sizeof(int32_t) : 0);
+        const size_t reuse = c->d_twod_bytes + c->d_bound_bytes; // already held by this context
         chunk_cap = std::min<size_t>(chunk_cap, std::max<size_t>(16, (free_b / 4 + reuse) / per_query));
     }
     if (const char *e = std::getenv("HYAS_CHUNK"))
@@ -846,7 +888,6 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     int drivers_cfg = 0;
     if (const char *e = std::getenv("HYAS_DRIVERS"))
         drivers_cfg = std::max(1, std::atoi(e));
-    const bool trace_on = std::getenv("HYAS_TRACE") != nullptr;
     // rounds between the pairs of timing events behind hyas_kernel_ms (the figure is scaled up from the timed launches):
     // every round for large calls, every 16th where a round is short enough for two event records to show
     const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : (n <= 64 ? 16 : 1);
@@ -887,6 +928,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     const size_t o_succ = take(DEPTH * (res_stride(nodes_max) + HYAS_MAX_GROUPS * 512));
     const size_t child_stride = (nodes_max * sizeof(StepIn) + 255) & ~(size_t)255; // device side only
     const size_t o_child = take((DEPTH - 1) * child_stride + 256);
+    // changes of cell state for the successor filter, per node of the launch before: K pushes and the pop that follows
+    const size_t upd_per_node = (size_t)K + 1, upd_max = filter_on ? nodes_max * upd_per_node : 0;
+    const size_t o_upd = take(upd_max * sizeof(CellUpd) + 256);
     // set-up staging, per buffer set: goals, poses {start, goal}, relative poses for the table lookup, their results
     struct PrepOff
     {
@@ -910,10 +954,16 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
     // the popped nodes go into device memory the host can store into, where there is such memory, else into the
     // pinned host block; r_in: where the host writes them, k_in: where the kernel reads them
-    if ((rc = ensure_nodes(c, nodes_max * sizeof(StepIn))) != HYAS_OK)
+    const size_t nodes_bytes = (nodes_max * sizeof(StepIn) + 255) & ~(size_t)255;
+    if ((rc = ensure_nodes(c, nodes_bytes + upd_max * sizeof(CellUpd) + 256)) != HYAS_OK)
         return rc;
     StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
     const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
+    // the filter's updates travel the same way, behind the nodes
+    CellUpd *const r_upd = c->d_nodes ? (CellUpd *)((char *)c->d_nodes + nodes_bytes) : (CellUpd *)(hs + o_upd);
+    const CellUpd *const k_upd = c->d_nodes ? (const CellUpd *)((char *)c->d_nodes + nodes_bytes) : (const CellUpd *)(hd + o_upd);
+    if (filter_on && (rc = ensure_buffer(c, (void **)&c->d_bound, &c->d_bound_bytes, cn_max * cells3d * sizeof(int32_t))) != HYAS_OK)
+        return rc;
     if (!c->prep_stream)
     {
         // lowest priority: streams of another priority get a hardware queue of their own (the round streams share the
@@ -972,6 +1022,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         {
             Query &q = Q[i];
             const float *p = poses + 6 * i;
+            q.qi = (uint32_t)i;
             q.goal = h_goal[i];
             q.start = SNode{p[0], p[1], p[2], 999.f, 0.f, 0, -1, -1, -1, -1}; // Node3D(): g = 999, prim = 0
             {
@@ -1093,6 +1144,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             size_t s0 = 0, ns = 0; // first query, nodes in flight
             size_t base = 0;       // first node slot of the group in the staging blocks
             std::atomic<uint32_t> claim{0}; // nodes of the launch being assembled that the workers have claimed
+            // successor filter: the cell changes each worker has seen this round, and their place in the launch
+            std::vector<std::unique_ptr<CellUpd[]>> upd; // one buffer of upd_cap entries per worker
+            std::atomic<uint32_t> upd_claim{0};
+            size_t upd_base = 0, upd_cap = 0, n_upd = 0;
             double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0, t_sub = 0, t_turn = 0, t_idle = 0, t_done = 0;
             int64_t launches = 0, rounds = 0, timed_launches = 0;
             bool timed = false; // the round in flight carries the two timing events
@@ -1102,6 +1157,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         {
             G[gi].s0 = (size_t)gi * gcap;
             G[gi].base = (size_t)gi * gslots;
+            G[gi].upd_base = (size_t)gi * gslots * upd_per_node, G[gi].upd_cap = filter_on ? gslots * upd_per_node : 0;
             for (size_t i = G[gi].s0; i < std::min(cn, G[gi].s0 + gcap); ++i)
                 G[gi].live.push_back((uint32_t)i);
         }
@@ -1112,7 +1168,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::atomic<uint64_t> spec_hits{0}, deep_hits{0}, ahead_hits{0}, ahead_sent{0}, open_sent{0}, miss_child{0}, miss_other{0};
         std::atomic<uint64_t> cyc_consume{0}, cyc_advance{0}, cyc_next{0}, cyc_copy{0}; // host time by part, HYAS_TRACE only
         std::atomic<uint64_t> pr_dup{0}, pr_cell{0}, pr_push{0}, pr_chain{0}, pr_heads{0}, pr_succ{0}, pr_pushed{0};
-        g_probe_on = trace_on;
+        std::atomic<uint64_t> pr_closed{0}, pr_worse{0}, pr_tie{0}, pr_dupdrop{0};
         std::vector<std::atomic<uint64_t>> probe_hist(128);
         auto tick = [trace_on]() -> uint64_t { return trace_on ? __builtin_ia32_rdtsc() : 0; };
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1148,6 +1204,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             for (int w = 0; w <= nw; ++w)
                 g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
             g.claim.store(0, std::memory_order_relaxed);
+            g.upd_claim.store(0, std::memory_order_relaxed);
+            while (filter_on && (int)g.upd.size() < nw)
+                g.upd.emplace_back(new CellUpd[g.upd_cap + 1]);
             // this round's widths: the call's, or what the queries still alive leave room for (every group takes the
             // call to be as thinned out as itself)
             int r_spec_k = spec_k, r_tree = tree_cfg, r_ahead = ahead_cfg;
@@ -1163,6 +1222,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             }
             gp.run_parts([&](int w) {
                 uint64_t hits = 0, deep = 0, ahead = 0, n_ahead_sent = 0, n_open_sent = 0, c_consume = 0, c_advance = 0, c_next = 0;
+                UpdSink my_upd{filter_on ? g.upd[w].get() : nullptr, 0, filter_on ? (uint32_t)g.upd_cap : 0u};
+                UpdSink *const upd = filter_on ? &my_upd : nullptr;
                 for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
                 {
                     Query &q = Q[g.live[k]];
@@ -1195,7 +1256,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                                     if (q.spec[i] < 0 && q.ahead_parent[i] == at)
                                         wanted.cand[wanted.n] = q.ahead_cand[i], wanted.id[wanted.n] = -1, wanted_at[wanted.n] = i, ++wanted.n;
                             D.consume(q, L[lvl].ok[sl], L[lvl].len[sl], L[lvl].cnt[sl], L[lvl].succ + sl * K, lvl + 1 < DEPTH ? &best_child : nullptr,
-                                      wanted.n ? &wanted : nullptr);
+                                      wanted.n ? &wanted : nullptr, upd);
                             if (best_child >= 0 && n_ans < ANS_CAP)
                                 ans_id[n_ans] = best_child, ans_lvl[n_ans] = (uint8_t)(lvl + 1), ans_at[n_ans] = (uint8_t)at, ++n_ans;
                             for (int w = 0; w < wanted.n; ++w)
@@ -1213,7 +1274,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             }
                             const uint64_t c1 = tick();
                             const int32_t consumed = q.cur;
-                            want = !q.done && D.advance(q);
+                            want = !q.done && D.advance(q, upd);
                             c_consume += c1 - c0, c_advance += tick() - c1;
                             if (!want)
                                 break;
@@ -1271,7 +1332,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             q.spec_w = deepest ? std::min(r_spec_k - 1, deepest + 2) : std::max(spec_floor, q.spec_w - 1);
                     }
                     else
-                        want = !q.done && D.advance(q);
+                        want = !q.done && D.advance(q, upd);
                     wants[qi] = want ? 1 : 0;
                     const uint64_t c2 = tick();
                     if (want)
@@ -1390,7 +1451,16 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     for (int i = 0; i < Q[qi].nspec; ++i)
                         r_in[g.base + at++] = stage[qi * KS + i];
                 }
-                if (c->d_nodes && mine)
+                // the filter's updates likewise; what does not fit is left out (a bound that stays too high drops less)
+                if (my_upd.n)
+                {
+                    const uint32_t have = my_upd.n, u0 = g.upd_claim.fetch_add(have, std::memory_order_relaxed);
+                    const size_t room = u0 < g.upd_cap ? g.upd_cap - u0 : 0, take_n = std::min<size_t>(have, room);
+                    CellUpd *dst = r_upd + g.upd_base + u0;
+                    for (size_t i = 0; i < take_n; ++i)
+                        dst[i] = my_upd.p[i];
+                }
+                if (c->d_nodes && (mine || my_upd.n))
                     __builtin_ia32_sfence(); // stores into device memory leave this core's write-combining buffers
                 if (trace_on)
                 {
@@ -1398,6 +1468,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     cyc_next.fetch_add(c_next, std::memory_order_relaxed), cyc_copy.fetch_add(tick() - c3, std::memory_order_relaxed);
                     pr_dup.fetch_add(t_probe.dup), pr_cell.fetch_add(t_probe.cell), pr_push.fetch_add(t_probe.push), pr_chain.fetch_add(t_probe.chain);
                     pr_heads.fetch_add(t_probe.heads), pr_succ.fetch_add(t_probe.succ), pr_pushed.fetch_add(t_probe.pushed);
+                    pr_closed.fetch_add(t_probe.drop_closed), pr_worse.fetch_add(t_probe.drop_worse), pr_tie.fetch_add(t_probe.drop_tie);
+                    pr_dupdrop.fetch_add(t_probe.drop_dup);
                     t_probe = ConsumeProbe();
                 }
             });
@@ -1407,6 +1479,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     g.keep.push_back(qi);
             g.live.swap(g.keep); // queries that finished drop out
             g.ns = g.claim.load(std::memory_order_relaxed);
+            g.n_upd = std::min<size_t>(g.upd_claim.load(std::memory_order_relaxed), g.upd_cap);
             g.t_host += now() - t0;
             return g.ns != 0;
         };
@@ -1432,9 +1505,11 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 slice(g, l, p_succ, p_len, p_ok, p_cnt);
                 const StepIn *d_in = l == 0 ? k_in + s0 : (const StepIn *)(ds + o_child + (l - 1) * child_stride) + s0;
                 StepIn *d_child = l + 1 < DEPTH ? (StepIn *)(ds + o_child + l * child_stride) + s0 : nullptr;
+                // the first launch of a round brings the cell bounds up to date, every launch tests against them
+                const CellFilter filter{filter_on ? c->d_bound : nullptr, (uint32_t)cells3d, k_upd + g.upd_base, l == 0 ? (uint32_t)g.n_upd : 0u};
                 launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
                              (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
-                             c->stats_mode, st, d_child, P_analytic);
+                             c->stats_mode, st, d_child, P_analytic, filter);
             }
             if (g.timed)
                 (void)hipEventRecord(ev[1], st);
@@ -1507,6 +1582,12 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         };
         const double wall_setup = cur.t_all;
         c->pools->driver_pools(n_drivers, threads_per_driver);
+        if (filter_on)
+        {
+            // every cell of every query of the chunk unseen: +inf
+            HYAS_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_bound, 0x7F800000, cn * cells3d, c->stream));
+            HYAS_HIP(c, hipStreamSynchronize(c->stream));
+        }
         {
             std::vector<std::thread> drivers;
             for (int d = 1; d < n_drivers; ++d)
@@ -1557,6 +1638,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             "cell lookup %.3e cycles, %.3e pushes %.3e cycles\n",
                     (double)pr_succ.load(), (double)pr_dup.load(), (double)pr_heads.load(), (double)pr_chain.load(), (double)pr_cell.load(),
                     (double)pr_pushed.load(), (double)pr_push.load());
+        if (trace_on)
+            fprintf(stderr, "hyas successors dropped: cell closed %.3e, cell open with a cost not worse %.3e, same cell beyond the tie breaker %.3e, "
+                            "duplicate of an open-list entry %.3e\n",
+                    (double)pr_closed.load(), (double)pr_worse.load(), (double)pr_tie.load(), (double)pr_dupdrop.load());
         if (trace_on)
             for (int gi = 0; gi < ng; ++gi)
                 fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host %.3f s launch %.3f s wait %.3f s\n",

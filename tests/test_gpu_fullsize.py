@@ -148,7 +148,7 @@ def test_large_map_query_blocks(oracle_built):
 
 def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
     """How the host schedules the search (query groups in flight, worker threads, nodes expanded ahead of time per
-    query, nodes sent ahead of their existence, launches per round, chunk size) must not show in any output: result records, expansion order and paths are bit-identical."""
+    query, nodes sent ahead of their existence, launches per round, chunk size, successors dropped on the GPU or on the host) must not show in any output: result records, expansion order and paths are bit-identical."""
     h = maze_ctx
     S, G = make_queries(h.collision, 300, 77, 50, 50)
     base = h.plan_batch(S, G)
@@ -165,9 +165,12 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
                 dict(HYAS_AHEAD="1", HYAS_AHEAD_WIDTH="4"), dict(HYAS_PIN="0"), dict(HYAS_LIVE_WIDTHS="0"),
                 dict(HYAS_GROUPS="1"), dict(HYAS_GROUPS="7", HYAS_CHUNK="61"),
                 dict(HYAS_TREE="42", HYAS_SPEC="10", HYAS_SPEC_ADAPT="0"), dict(HYAS_TREE="7", HYAS_DEPTH="2"), dict(HYAS_TREE="48", HYAS_SPEC="1"), dict(HYAS_AHEAD="2", HYAS_AHEAD_WIDTH="2", HYAS_SPEC="8"),
-                dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"), dict()):
+                dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"),
+                dict(HYAS_FILTER="0"), dict(HYAS_FILTER="0", HYAS_DEPTH="2"), dict(HYAS_FILTER="1", HYAS_NODES_IN_HOST_MEMORY="1", HYAS_GROUPS="3"),
+                dict(HYAS_FILTER="1", HYAS_CHUNK="50", HYAS_TREE="20"), dict()):
         for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS",
-                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH", "HYAS_PIN", "HYAS_TREE", "HYAS_LIVE_WIDTHS"):
+                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH", "HYAS_PIN", "HYAS_TREE", "HYAS_LIVE_WIDTHS",
+                  "HYAS_FILTER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
