@@ -42,6 +42,20 @@ struct CellFilter
     uint32_t n_upd;
 };
 
+// Results of a search round as the host reads them while the kernel is still running: one block of `units` 16-byte units
+// per node of the launch, every unit carrying the round's tag in its last word, so that the host can tell, unit by unit
+// and without any completion signal, whether what it reads is this round's (a unit is stored by one lane in one 16-byte
+// store).  Unit 0, the analytic shot: {length bits, verdict, 0, tag}; unit 1, the successors: {count byte as in the
+// count array, 0, 0, tag}; units 2 + 2j and 3 + 2j, successor j: {x, y, t, tag << 9 | child mark << 8 | (motion-set
+// entry + 1) << 3 | primitive} and {g, h, idx, tag}.  Tags are 23 bits and never 0.
+struct RoundOut
+{
+    uint4 *base;    // null: results go to the plain arrays
+    uint32_t units; // per node: 2 + 2 * successor slots
+    uint32_t tag;
+};
+#define ROUND_TAG_MASK 0x7FFFFFu
+
 void launch_collision(const DevMap &m, int mode, const float *xyt, const float *pred_xy, size_t n, uint8_t *out, hipStream_t s);
 // map ingest: occupancy values, occupancy bit tiles (padded may be null), per-key in-range lists.
 void launch_occupancy(const uint8_t *cost, size_t n, int8_t *occ, hipStream_t s);
@@ -65,10 +79,14 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
                    hyas_succ *succ, unsigned long long *stats, int stats_mode, hipStream_t s);
 void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                     uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s);
+// stores `value` into *flag (pinned host memory) once everything launched on `s` before it has finished: the host spins on
+// the word instead of asking the runtime (hipStreamQuery answers about 10 us later than the word arrives)
+void launch_flag(uint32_t *flag, uint32_t value, hipStream_t s);
 hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode);
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                  int stats_mode, hipStream_t s, StepIn *child = nullptr, bool child_shoot = false, CellFilter filter = CellFilter{nullptr, 0, nullptr, 0});
+                  int stats_mode, hipStream_t s, StepIn *child = nullptr, bool child_shoot = false, CellFilter filter = CellFilter{nullptr, 0, nullptr, 0},
+                  RoundOut out = RoundOut{nullptr, 0, 0});
 // child (optional, n records in device memory): the launch also writes, for every node, the input record of its
 // lowest-f successor (shoot = child_shoot; STEP_DEAD when the node has none), ready to be the `in` of a further launch
 // on the same stream, and marks that successor's record with bit 0 of pad.  A search round tags every successor

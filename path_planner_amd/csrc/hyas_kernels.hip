@@ -704,6 +704,12 @@ __global__ void __launch_bounds__(256) k_table_lookup(DevMap m, const float *__r
         cost[i] = table_cost(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]);
 }
 
+__global__ void __launch_bounds__(64) k_flag(uint32_t *flag, uint32_t value)
+{
+    if (threadIdx.x == 0)
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(256) k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -982,7 +988,8 @@ template <int MODE, int ADAPT>
 __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__restrict__ in, uint32_t n, const hyas_goal *__restrict__ goals,
                                             const float *__restrict__ twod, uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
                                             unsigned long long *stats, Quad *s_quads, uint32_t block, StepIn *__restrict__ child = nullptr,
-                                            uint32_t flags = 0, const int32_t *__restrict__ bound = nullptr, uint32_t bound_cells = 0)
+                                            uint32_t flags = 0, const int32_t *__restrict__ bound = nullptr, uint32_t bound_cells = 0,
+                                            RoundOut ro = RoundOut{nullptr, 0, 0})
 {
     constexpr int LANES = ExpandShape<ADAPT>::LANES, NODES = ExpandShape<ADAPT>::NODES, CAND = ExpandShape<ADAPT>::CAND, SUB = ExpandShape<ADAPT>::SUB;
     const int tid = threadIdx.x;
@@ -1161,17 +1168,38 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
     if (ok)
     {
         int pos = __popc(mask & ((1u << sl) - 1u));
-        succ[(size_t)slot * m.n_slots + pos] = s;
+        if (ro.base)
+        {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 *unit = reinterpret_cast<u32x4 *>(ro.base) + (size_t)slot * ro.units + 2 + 2 * pos;
+            const u32x4 a = {__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.t),
+                             ro.tag << 9 | (uint32_t)(s.pad & 1u) << 8 | (uint32_t)(s.pad >> 8) << 3 | (uint32_t)prim};
+            const u32x4 b = {__float_as_uint(s.g), __float_as_uint(s.h), (uint32_t)s.idx, ro.tag};
+            __builtin_nontemporal_store(a, unit);
+            __builtin_nontemporal_store(b, unit + 1);
+        }
+        else
+            succ[(size_t)slot * m.n_slots + pos] = s;
     }
     const bool writer = in_launch && seg_lane && sl == 0 && part == 0;
     if (writer) // low nibble: emitted successors, high nibble: candidates that got a verdict
-        count[slot] = overflow ? (uint8_t)0xFF : (uint8_t)(__popc(mask) | (__popc(emask) << 4));
+    {
+        const uint8_t cnt = overflow ? (uint8_t)0xFF : (uint8_t)(__popc(mask) | (__popc(emask) << 4));
+        if (ro.base)
+        {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 e = {(uint32_t)cnt, 0u, 0u, ro.tag};
+            __builtin_nontemporal_store(e, reinterpret_cast<u32x4 *>(ro.base) + (size_t)slot * ro.units + 1);
+        }
+        else
+            count[slot] = cnt;
+    }
     if (MODE == 1)
     {
         uint32_t walked = (seg_lane && evaluated && part == 0) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
         for (int off = CAND / 2; off > 0; off >>= 1)
             walked += __shfl_xor(walked, off, 64);
-        if (writer)
+        if (writer && live)
         {
             atomicAdd(&stats[3], (unsigned long long)__popc(emask));
             atomicAdd(&stats[4], (unsigned long long)walked);
@@ -1198,8 +1226,20 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
 template <int MODE, int CURVE>
 __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restrict__ in, const hyas_goal *__restrict__ goals,
                                           const double *__restrict__ seg_tab, uint32_t seg_cap, uint8_t *__restrict__ shot_ok,
-                                          float *__restrict__ shot_len, unsigned long long *stats, Quad *s_quads, uint32_t slot)
+                                          float *__restrict__ shot_len, unsigned long long *stats, Quad *s_quads, uint32_t slot,
+                                          RoundOut ro = RoundOut{nullptr, 0, 0})
 {
+    // the verdict leaves in one store: into the arrays, or into unit 0 of the node's block
+    auto answer = [&](uint8_t ok, float len) {
+        if (ro.base)
+        {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = {__float_as_uint(len), (uint32_t)ok, 0u, ro.tag};
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(ro.base) + (size_t)slot * ro.units);
+        }
+        else
+            shot_ok[slot] = ok, shot_len[slot] = len;
+    };
     __shared__ rs::Path s_path;
     __shared__ rs::Prefix s_prefix;
     __shared__ db::Path s_dubins;
@@ -1215,7 +1255,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     if ((node.shoot & 1u) == 0) // uniform across the workgroup
     {
         if (tid == 0)
-            shot_ok[slot] = 0, shot_len[slot] = 0;
+            answer(0, 0.f);
         return;
     }
     constexpr bool STATS = MODE == 1, CLOCKS = MODE == 2;
@@ -1609,8 +1649,7 @@ __device__ __forceinline__ void shot_role(const DevMap &m, const StepIn *__restr
     if (tid == 0)
     {
         // an empty sample list is "no shot" (path_vec.size() == 0, src/hybrid_a_star.cpp:524)
-        shot_ok[slot] = (!collided && nsamp > 0) ? 1 : 0;
-        shot_len[slot] = (float)length;
+        answer((!collided && nsamp > 0) ? 1 : 0, (float)length);
     }
     if (STATS)
     {
@@ -1675,7 +1714,7 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
                                                                         uint8_t *__restrict__ shot_ok, float *__restrict__ shot_len,
                                                                         uint8_t *__restrict__ count, hyas_succ *__restrict__ succ,
                                                                         unsigned long long *stats, StepIn *__restrict__ child, uint32_t flags,
-                                                                        CellFilter filter)
+                                                                        CellFilter filter, RoundOut ro)
 {
     __shared__ Quad s_quads[STEP_LDS_QUADS];
     const uint32_t n_upd_blocks = (filter.n_upd + ROUND_THREADS - 1) / ROUND_THREADS;
@@ -1693,9 +1732,9 @@ __global__ void __launch_bounds__(ROUND_THREADS, STEP_MIN_WAVES) k_round(DevMap 
     }
     const uint32_t block = blockIdx.x - n_upd_blocks;
     if (block < n)
-        shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, block);
+        shot_role<MODE, CURVE>(m, in, goals, seg_tab, seg_cap, shot_ok, shot_len, stats, s_quads, block, ro);
     else
-        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, block - n, child, flags, filter.bound, filter.cells);
+        expand_role<MODE == 2 ? 0 : MODE, ADAPT>(m, in, n, goals, twod, count, succ, stats, s_quads, block - n, child, flags, filter.bound, filter.cells, ro);
 }
 
 // The accepted curves of n queries, one workgroup each: samples {x, y, t} of
@@ -2309,25 +2348,25 @@ struct LaunchRound
     template <int ADAPT>
     static void with(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
                      uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, StepIn *child,
-                     uint32_t child_shoot, CellFilter filter, hipStream_t s)
+                     uint32_t child_shoot, CellFilter filter, RoundOut ro, hipStream_t s)
     {
         constexpr uint32_t nodes = ExpandShape<ADAPT>::NODES;
         const dim3 grid((filter.n_upd + ROUND_THREADS - 1) / ROUND_THREADS + n + (n + nodes - 1) / nodes);
         hipLaunchKernelGGL((k_round<MODE, CURVE, ADAPT>), grid, dim3(ROUND_THREADS), 0, s, m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len,
-                           count, succ, stats, child, child_shoot, filter);
+                           count, succ, stats, child, child_shoot, filter, ro);
     }
     static void go(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab, uint32_t seg_cap,
                    uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats, StepIn *child, uint32_t child_shoot,
-                   CellFilter filter, hipStream_t s)
+                   CellFilter filter, RoundOut ro, hipStream_t s)
     {
         if constexpr (MODE == 0) // the adaptive variants exist without counters only
         {
             if (m.ad_mode == 1)
-                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, s);
+                return with<1>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, ro, s);
             if (m.ad_mode == 2)
-                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, s);
+                return with<2>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, ro, s);
         }
-        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, s);
+        with<0>(m, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child, child_shoot, filter, ro, s);
     }
 };
 
@@ -2362,6 +2401,9 @@ hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode)
         mode = 0;
     hipError_t e = hipSuccess;
     dispatch_mode_curve<ResolveRound>(m, mode, &e);
+    hipFuncAttributes attr;
+    if (e == hipSuccess)
+        e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_flag));
     return e;
 }
 
@@ -2376,7 +2418,7 @@ void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal 
 
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,
-                  int stats_mode, hipStream_t s, StepIn *child, bool child_shoot, CellFilter filter)
+                  int stats_mode, hipStream_t s, StepIn *child, bool child_shoot, CellFilter filter, RoundOut out)
 {
     if (!n)
         return;
@@ -2386,8 +2428,10 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
     if (!filter.bound)
         filter = CellFilter{nullptr, 0, nullptr, 0};
     dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child,
-                                     (child_shoot ? ROUND_CHILD_SHOOT : 0u) | ROUND_TAG_CANDIDATE, filter, s);
+                                     (child_shoot ? ROUND_CHILD_SHOOT : 0u) | ROUND_TAG_CANDIDATE, filter, out, s);
 }
+
+void launch_flag(uint32_t *flag, uint32_t value, hipStream_t s) { hipLaunchKernelGGL(k_flag, dim3(1), dim3(64), 0, s, flag, value); }
 
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s)
 {

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <thread>
 
+#include <emmintrin.h>
 #include <sched.h>
 
 #include "hyas_ctx.h"
@@ -750,24 +751,21 @@ int host_threads()
 struct SearchPools
 {
     std::unique_ptr<Pool> main;
-    std::vector<std::unique_ptr<Pool>> driver;
-    int driver_threads = 0;
     Pool &main_pool(int threads)
     {
         if (!main || main->size() != std::max(1, threads))
             main.reset(new Pool(threads));
         return *main;
     }
-    // n pools of `threads` threads each
-    bool pinned = false;
-    int pin_total = 0;
-    void driver_pools(int n, int threads)
+    // the worker threads of the rounds, each on a CPU of its own where the affinity mask has enough of them
+    std::unique_ptr<Pool> round;
+    bool round_pinned = false;
+    Pool &round_pool(int threads)
     {
-        const bool pin = pinning_on(n * threads);
-        if (driver_threads != threads || pinned != pin || (pin && pin_total != n * threads))
-            driver.clear(), driver_threads = threads, pinned = pin, pin_total = n * threads;
-        while ((int)driver.size() < n)
-            driver.emplace_back(new Pool(threads, pin ? (int)driver.size() * threads : -1, pin_total));
+        const bool pin = pinning_on(threads);
+        if (!round || round->size() != std::max(1, threads) || round_pinned != pin)
+            round.reset(), round.reset(new Pool(threads, pin ? 0 : -1, threads)), round_pinned = pin;
+        return *round;
     }
 };
 
@@ -776,9 +774,6 @@ void free_search_pools(hyas_ctx *c)
     delete c->pools;
     c->pools = nullptr;
 }
-
-// queries per group
-static size_t gcap_hint(size_t cn, int ng) { return (cn + ng - 1) / ng; }
 
 int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t n, hyas_result *out)
 {
@@ -885,9 +880,6 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     if (m.ad_mode != 0)
         tree_cfg = 0;
     const int ahead_nodes = tree_cfg ? tree_cfg : ahead_cfg * ahead_width; // nodes of a query that do not exist yet, at most
-    int drivers_cfg = 0;
-    if (const char *e = std::getenv("HYAS_DRIVERS"))
-        drivers_cfg = std::max(1, std::atoi(e));
     // rounds between the pairs of timing events behind hyas_kernel_ms (the figure is scaled up from the timed launches):
     // every round for large calls, every 16th where a round is short enough for two event records to show
     const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : (n <= 64 ? 16 : 1);
@@ -910,7 +902,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     // results of one group of `cap` queries: successors, shot length, shot verdict, successor count
-    auto res_stride = [&](size_t cap) { return ((cap * K * sizeof(hyas_succ) + cap * sizeof(float) + 2 * cap + 64) + 255) & ~(size_t)255; };
+    // results of one group of `cap` node slots: one block of 2 + 2 K sixteen-byte units per node (RoundOut, hyas_kernels.h)
+    const size_t out_units = 2 + 2 * (size_t)K;
+    auto res_stride = [&](size_t cap) { return (cap * out_units * 16 + 255) & ~(size_t)255; };
     const int spec_k = spec_cfg; // open-list entries of a query in one launch, at most (widths fixed for the call)
     // nodes of a query in one launch, at most
     const size_t KS = widths_follow_live ? (size_t)SHARE_MAX : (size_t)(spec_k + ahead_nodes);
@@ -924,13 +918,14 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     const size_t slots_max = cn_max + HYAS_MAX_GROUPS;
     // nodes of all groups together, at most (the sum of group_slots over any split into at most HYAS_MAX_GROUPS groups)
     const size_t nodes_max = widths_follow_live ? SHARE_MIN * slots_max + ROUND_NODES + (size_t)SHARE_MAX * HYAS_MAX_GROUPS : slots_max * KS;
-    const size_t o_in = take(nodes_max * sizeof(StepIn));
+    // (two sets of node slots and cell updates: a launch may still be reading its own while the next one's are written)
+    const size_t o_in = take(2 * nodes_max * sizeof(StepIn));
     const size_t o_succ = take(DEPTH * (res_stride(nodes_max) + HYAS_MAX_GROUPS * 512));
     const size_t child_stride = (nodes_max * sizeof(StepIn) + 255) & ~(size_t)255; // device side only
     const size_t o_child = take((DEPTH - 1) * child_stride + 256);
     // changes of cell state for the successor filter, per node of the launch before: K pushes and the pop that follows
     const size_t upd_per_node = (size_t)K + 1, upd_max = filter_on ? nodes_max * upd_per_node : 0;
-    const size_t o_upd = take(upd_max * sizeof(CellUpd) + 256);
+    const size_t o_upd = take(2 * upd_max * sizeof(CellUpd) + 256);
     // set-up staging, per buffer set: goals, poses {start, goal}, relative poses for the table lookup, their results
     struct PrepOff
     {
@@ -954,8 +949,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     HYAS_HIP(c, hipHostGetDevicePointer((void **)&hd, c->h_scratch, 0));
     // the popped nodes go into device memory the host can store into, where there is such memory, else into the
     // pinned host block; r_in: where the host writes them, k_in: where the kernel reads them
-    const size_t nodes_bytes = (nodes_max * sizeof(StepIn) + 255) & ~(size_t)255;
-    if ((rc = ensure_nodes(c, nodes_bytes + upd_max * sizeof(CellUpd) + 256)) != HYAS_OK)
+    const size_t nodes_bytes = (2 * nodes_max * sizeof(StepIn) + 255) & ~(size_t)255;
+    if ((rc = ensure_nodes(c, nodes_bytes + 2 * upd_max * sizeof(CellUpd) + 256)) != HYAS_OK)
         return rc;
     StepIn *const r_in = c->d_nodes ? (StepIn *)c->d_nodes : h_in;
     const StepIn *const k_in = c->d_nodes ? (const StepIn *)c->d_nodes : (const StepIn *)(hd + o_in);
@@ -1127,28 +1122,52 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         const int ng = (int)std::max<size_t>(1, std::min<size_t>(want_groups, cn / 32 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
         const size_t gslots = group_slots(gcap, (size_t)ng); // node slots per group
-        const int max_drivers = drivers_cfg ? drivers_cfg : std::max(1, ng / 2);
-        const int n_drivers = std::max(1, std::min(std::min(ng, max_drivers), pool.size()));
-        const int threads_per_driver =
-            (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size() / n_drivers, gcap_hint(cn, ng) * ((ng + n_drivers - 1) / n_drivers) / 8 + 1));
+        // worker threads of the rounds: one per eight queries of the chunk, at most the host threads of the call
+        const int n_workers = (int)std::max<size_t>(1, std::min<size_t>((size_t)pool.size(), cn / 8 + 1));
         const double wall_flood = cur.t_gpu;
 
         // rounds.  The chunk's queries form groups that advance independently: every group has its own stream and
-        // slice of the staging block; up to four driver threads (with helper threads) each look after a share of
-        // the groups.  While a group's kernel runs, its driver pushes successors, pops the next nodes and launches
-        // for its other groups; nothing is shared between groups but the map.
+        // slice of the staging block, and nothing is shared between groups but the map.  A round of a group is a host
+        // part (push the successors of the launch that has come back, pop the next nodes, stage them) and a launch.
+        // A host part is cut into pieces of a few queries.  Every worker thread has a home range of every group's pieces (the
+        // same queries every round: their heaps, cell maps and duplicate hashes stay in that core's cache) and takes
+        // those first, then pieces of the other workers' ranges that are still waiting, so that a host part is finished
+        // by whoever is free and its next launch leaves as early as possible.  Host parts are released in the order in
+        // which the launches come back and every worker goes through them in that order; no worker waits for another: the
+        // one that finishes a host part's last piece launches the group and releases its next host part at once: nobody
+        // waits for the launch to finish, a worker waits for the answer it needs next (see `unit`).
+        enum : int { G_HOST = 0, G_FINISHED = 2 };
         struct Group
         {
+            // the host part being worked on: result blocks, widths, who has still to do a share of it
+            const char *out[HYAS_MAX_DEPTH] = {}; // results of the launch(es) before it, one block of out_units units per node
+            uint32_t read_tag = 0;                // ... and the tag their units carry
+            int r_spec_k = 0, r_tree = 0, r_ahead = 0;
+            size_t r_nodes = 0; // node slots of every query in the launch that follows this host part
+            bool r_adapt = false, have_results = false;
+            std::atomic<uint32_t> pieces_left{0}; // pieces of this host part that are not finished
+            uint32_t part_no = 0;
+            // worker w's home range of pieces: {host part (24 bits), end (20), next (20)} in one word, claimed by compare-and-swap
+            struct alignas(64) Cursor
+            {
+                std::atomic<uint64_t> v{0};
+            };
+            std::unique_ptr<Cursor[]> cur;
+            std::atomic<int> state{G_HOST};
+            std::atomic<uint64_t> host_ns{0}; // worker time spent in host parts (HYAS_TRACE)
+            // HYAS_TRACE, per host part: when it was released, when the first worker began and the last one ended; sums over the parts
+            uint64_t rel_ns = 0;
+            std::atomic<uint64_t> first_ns{0}, last_ns{0};
+            uint64_t sum_first = 0, sum_last = 0, parts = 0;
             std::vector<uint32_t> live, keep;
             std::vector<size_t> bounds;
             size_t s0 = 0, ns = 0; // first query, nodes in flight
             size_t base = 0;       // first node slot of the group in the staging blocks
-            std::atomic<uint32_t> claim{0}; // nodes of the launch being assembled that the workers have claimed
             // successor filter: the cell changes each worker has seen this round, and their place in the launch
             std::vector<std::unique_ptr<CellUpd[]>> upd; // one buffer of upd_cap entries per worker
             std::atomic<uint32_t> upd_claim{0};
             size_t upd_base = 0, upd_cap = 0, n_upd = 0;
-            double t_host = 0, t_launch = 0, t_wait = 0, k_ms = 0, t_sub = 0, t_turn = 0, t_idle = 0, t_done = 0;
+            double t_launch = 0, k_ms = 0, t_sub = 0, t_turn = 0, t_idle = 0, t_done = 0;
             int64_t launches = 0, rounds = 0, timed_launches = 0;
             bool timed = false; // the round in flight carries the two timing events
             int rc = HYAS_OK;
@@ -1165,66 +1184,123 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         std::vector<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
         std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
         const bool P_analytic = c->P.analytical_expansion != 0;
-        std::atomic<uint64_t> spec_hits{0}, deep_hits{0}, ahead_hits{0}, ahead_sent{0}, open_sent{0}, miss_child{0}, miss_other{0};
-        std::atomic<uint64_t> cyc_consume{0}, cyc_advance{0}, cyc_next{0}, cyc_copy{0}; // host time by part, HYAS_TRACE only
-        std::atomic<uint64_t> pr_dup{0}, pr_cell{0}, pr_push{0}, pr_chain{0}, pr_heads{0}, pr_succ{0}, pr_pushed{0};
-        std::atomic<uint64_t> pr_closed{0}, pr_worse{0}, pr_tie{0}, pr_dupdrop{0};
+        std::atomic<uint64_t> miss_child{0}, miss_other{0};
+        // what every worker counts for itself (summed after the rounds): answers used ahead of time, and with HYAS_TRACE
+        // the nodes sent, host time by part in timestamp-counter cycles and the figures of taking successors
+        struct alignas(64) Tally
+        {
+            uint64_t hits = 0, deep = 0, ahead = 0, ahead_sent = 0, open_sent = 0;
+            uint64_t c_consume = 0, c_advance = 0, c_next = 0, c_copy = 0;
+            ConsumeProbe probe;
+        };
+        std::vector<Tally> tally((size_t)n_workers);
         std::vector<std::atomic<uint64_t>> probe_hist(128);
         auto tick = [trace_on]() -> uint64_t { return trace_on ? __builtin_ia32_rdtsc() : 0; };
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        // where a group's results of the current round lie in the staging block (laid out for its current size)
-        auto slice = [&](const Group &g, size_t lvl, size_t &p_succ, size_t &p_len, size_t &p_ok, size_t &p_cnt) {
-            size_t o = o_succ + ((&g - G) * DEPTH + lvl) * res_stride(gslots);
-            p_succ = o, o += (g.ns * K * sizeof(hyas_succ) + 15) & ~(size_t)15;
-            p_len = o, o += (g.ns * sizeof(float) + 15) & ~(size_t)15;
-            p_ok = o, o += (g.ns + 15) & ~(size_t)15;
-            p_cnt = o, o += (g.ns + 15) & ~(size_t)15;
-        };
-        // host part of a round for one group: push the successors of the round that just finished (if any), pop
-        // the next node of every query; false when all queries of the group have finished
-        auto host_round = [&](Group &g, Pool &gp, bool have_results) -> bool {
-            const double t0 = now();
-            struct Level
+        // where a group's results lie in the staging block
+        auto out_offset = [&](const Group &g, size_t lvl) { return o_succ + ((&g - G) * DEPTH + lvl) * res_stride(gslots); };
+        std::atomic<bool> abort_all{false};
+        // One unit of a node's result block, once it carries the round's tag (in the low 23 bits of its last word shifted
+        // down by `shift`).  The kernel stores a unit in one 16-byte store and the load here is one 16-byte load, so a
+        // unit is seen whole or not at all.  False when the call is being abandoned.
+        auto stuck = [&]() {
+            for (int gi = 0; gi < ng; ++gi)
             {
-                const hyas_succ *succ;
-                const float *len;
-                const uint8_t *ok, *cnt;
-            } L[HYAS_MAX_DEPTH];
-            for (size_t l = 0; l < DEPTH; ++l)
-            {
-                size_t p_succ, p_len, p_ok, p_cnt;
-                slice(g, l, p_succ, p_len, p_ok, p_cnt);
-                L[l] = Level{(const hyas_succ *)(hs + p_succ), (const float *)(hs + p_len), (const uint8_t *)(hs + p_ok), (const uint8_t *)(hs + p_cnt)};
+                const hipError_t e = hipStreamQuery(c->round_stream[gi]);
+                if (e != hipSuccess && e != hipErrorNotReady)
+                {
+                    G[gi].rc = HYAS_ENODEV;
+                    abort_all.store(true, std::memory_order_release);
+                }
+                (void)hipGetLastError();
             }
+        };
+        auto unit = [&](const char *p, uint32_t tag, int shift, uint32_t w[4]) -> bool {
+            for (uint64_t spins = 0;; ++spins)
+            {
+                _mm_storeu_si128((__m128i *)w, _mm_load_si128((const __m128i *)p));
+                if (((w[3] >> shift) & ROUND_TAG_MASK) == tag)
+                    return true;
+                __builtin_ia32_pause();
+                if ((spins & 0xFFFFF) == 0xFFFFF) // a launch that does not come back: ask the runtime what happened to it
+                {
+                    if (abort_all.load(std::memory_order_acquire))
+                        return false;
+                    if ((spins >> 20) % 64 == 63)
+                        stuck();
+                }
+            }
+        };
+        // host parts in the order of their release: entry k names the group of the k-th; a group has at most one host part
+        // outstanding, so no more than ng entries are ever ahead of the slowest worker
+        constexpr uint64_t ORDER_CAP = 4 * HYAS_MAX_GROUPS;
+        std::atomic<uint64_t> order[ORDER_CAP]; // group | host part << 8
+        std::atomic<uint64_t> released{0};
+        std::atomic<int> n_finished{0};
+        const size_t PIECE = std::getenv("HYAS_PIECE") ? (size_t)std::max(1, std::min(4096, std::atoi(std::getenv("HYAS_PIECE")))) : 2; // queries per piece
+        // Releases the next host part of a group to the workers: push the successors of the launch that has come back
+        // (if any), pop the next node of every query.  Called by the thread that saw the launch finish.
+        const int nw = n_workers;
+        auto begin_host_part = [&](Group &g, bool have_results) {
+            for (size_t l = 0; l < DEPTH; ++l)
+                g.out[l] = hs + out_offset(g, l);
+            g.read_tag = g.part_no; // the launch before this host part carried the number of the one before it
             // equal shares of the group's live queries, in index order: a query stays with the same worker from
             // round to round (its heap, cell map and duplicate hash stay in that core's cache) and only moves to a
             // neighbour when queries in front of it finish
-            const int nw = gp.size();
-            g.bounds.resize(nw + 1);
-            for (int w = 0; w <= nw; ++w)
-                g.bounds[w] = g.live.size() * (size_t)w / (size_t)nw;
-            g.claim.store(0, std::memory_order_relaxed);
+            const size_t n_pieces = (g.live.size() + PIECE - 1) / PIECE;
+            g.part_no = g.part_no == ROUND_TAG_MASK ? 1u : g.part_no + 1; // never 0: that is what a cleared unit carries
+            if (!g.cur)
+                g.cur.reset(new Group::Cursor[nw]);
             g.upd_claim.store(0, std::memory_order_relaxed);
             while (filter_on && (int)g.upd.size() < nw)
                 g.upd.emplace_back(new CellUpd[g.upd_cap + 1]);
             // this round's widths: the call's, or what the queries still alive leave room for (every group takes the
             // call to be as thinned out as itself)
-            int r_spec_k = spec_k, r_tree = tree_cfg, r_ahead = ahead_cfg;
-            bool r_adapt = spec_adapt;
+            g.r_spec_k = spec_k, g.r_tree = tree_cfg, g.r_ahead = ahead_cfg, g.r_adapt = spec_adapt;
             if (widths_follow_live)
             {
                 const int share = share_of(g.live.size() * (size_t)ng, ROUND_NODES);
                 const bool fixed = share >= SHARE_FIXED;
-                r_adapt = !fixed;
-                r_spec_k = fixed ? std::min(16, 4 + (share + 2) / 5) : 6;
-                r_tree = fixed && m.ad_mode == 0 ? share - r_spec_k : 0;
-                r_ahead = m.ad_mode == 0 ? 1 : 0;
+                g.r_adapt = !fixed;
+                g.r_spec_k = fixed ? std::min(16, 4 + (share + 2) / 5) : 6;
+                g.r_tree = fixed && m.ad_mode == 0 ? share - g.r_spec_k : 0;
+                g.r_ahead = m.ad_mode == 0 ? 1 : 0;
             }
-            gp.run_parts([&](int w) {
+            g.r_nodes = std::min<size_t>(KS, (size_t)g.r_spec_k + (size_t)(g.r_tree ? g.r_tree : g.r_ahead * ahead_width));
+            g.have_results = have_results;
+            if (trace_on)
+            {
+                if (g.rel_ns && g.last_ns.load())
+                    g.sum_first += g.first_ns.load() - g.rel_ns, g.sum_last += g.last_ns.load() - g.rel_ns, g.parts += 1;
+                g.rel_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                g.first_ns.store(~0ull), g.last_ns.store(0);
+            }
+            if (n_pieces == 0) // (only a group none of whose queries passed the pose checks)
+            {
+                g.state.store(G_FINISHED, std::memory_order_release);
+                n_finished.fetch_add(1, std::memory_order_acq_rel);
+                return;
+            }
+            g.pieces_left.store((uint32_t)n_pieces, std::memory_order_relaxed);
+            for (int w = 0; w < nw; ++w)
+                g.cur[w].v.store((uint64_t)g.part_no << 40 | (uint64_t)(n_pieces * (size_t)(w + 1) / (size_t)nw) << 20 | (uint64_t)(n_pieces * (size_t)w / (size_t)nw),
+                                 std::memory_order_release);
+            // (one releasing thread at a time: the caller holds the poll lock, or the workers have not started yet)
+            const uint64_t at = released.load(std::memory_order_relaxed);
+            order[at % ORDER_CAP].store((uint64_t)(&g - G) | (uint64_t)g.part_no << 8, std::memory_order_relaxed);
+            released.store(at + 1, std::memory_order_release);
+        };
+        // queries live[k0 .. k1) of a group's host part, done by worker w
+        auto host_piece = [&](Group &g, int w, size_t k0, size_t k1, UpdSink *upd) {
+            {
+                const bool have_results = g.have_results;
+                const int r_spec_k = g.r_spec_k, r_tree = g.r_tree, r_ahead = g.r_ahead;
+                const bool r_adapt = g.r_adapt;
+                const uint32_t read_tag = g.read_tag;
                 uint64_t hits = 0, deep = 0, ahead = 0, n_ahead_sent = 0, n_open_sent = 0, c_consume = 0, c_advance = 0, c_next = 0;
-                UpdSink my_upd{filter_on ? g.upd[w].get() : nullptr, 0, filter_on ? (uint32_t)g.upd_cap : 0u};
-                UpdSink *const upd = filter_on ? &my_upd : nullptr;
-                for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
+                const size_t r_nodes = g.r_nodes;
+                for (size_t k = k0; k < k1; ++k)
                 {
                     Query &q = Q[g.live[k]];
                     const uint32_t qi = g.live[k];
@@ -1255,8 +1331,34 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                                 for (int i = 1; i < q.nspec; ++i)
                                     if (q.spec[i] < 0 && q.ahead_parent[i] == at)
                                         wanted.cand[wanted.n] = q.ahead_cand[i], wanted.id[wanted.n] = -1, wanted_at[wanted.n] = i, ++wanted.n;
-                            D.consume(q, L[lvl].ok[sl], L[lvl].len[sl], L[lvl].cnt[sl], L[lvl].succ + sl * K, lvl + 1 < DEPTH ? &best_child : nullptr,
-                                      wanted.n ? &wanted : nullptr, upd);
+                            // the node's answer, unit by unit as it arrives: the successors' count, the successors, and
+                            // the shot's verdict where the search asks for it
+                            const char *blk = g.out[lvl] + sl * out_units * 16;
+                            uint32_t w[4], wb[4];
+                            hyas_succ got[HYAS_ADAPTIVE_SLOTS];
+                            if (!unit(blk + 16, read_tag, 0, w))
+                                return;
+                            const uint8_t cnt = (uint8_t)w[0];
+                            const int n_got = cnt == 0xFF ? 0 : (cnt & 15);
+                            for (int j = 0; j < n_got; ++j)
+                            {
+                                if (!unit(blk + 32 + 32 * j, read_tag, 9, w) || !unit(blk + 48 + 32 * j, read_tag, 0, wb))
+                                    return;
+                                hyas_succ &sj = got[j];
+                                std::memcpy(&sj.x, &w[0], 12), std::memcpy(&sj.g, &wb[0], 8);
+                                sj.idx = (int32_t)wb[2], sj.prim = (int8_t)(w[3] & 7u), sj.free = 1;
+                                sj.pad = (uint16_t)(((w[3] >> 3) & 31u) << 8 | ((w[3] >> 8) & 1u));
+                            }
+                            uint8_t shot_ok = 0;
+                            float shot_len = 0;
+                            if (q.shoot)
+                            {
+                                if (!unit(blk, read_tag, 0, w))
+                                    return;
+                                shot_ok = (uint8_t)w[1];
+                                std::memcpy(&shot_len, &w[0], 4);
+                            }
+                            D.consume(q, shot_ok, shot_len, cnt, got, lvl + 1 < DEPTH ? &best_child : nullptr, wanted.n ? &wanted : nullptr, upd);
                             if (best_child >= 0 && n_ans < ANS_CAP)
                                 ans_id[n_ans] = best_child, ans_lvl[n_ans] = (uint8_t)(lvl + 1), ans_at[n_ans] = (uint8_t)at, ++n_ans;
                             for (int w = 0; w < wanted.n; ++w)
@@ -1424,63 +1526,42 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     }
                     c_next += tick() - c2;
                 }
+                // The nodes of query k of the group's live list go into slots [k * r_nodes, (k + 1) * r_nodes) of the launch,
+                // copied by the thread that has just written them; slots the query does not use, and all slots of a query that
+                // has finished, carry STEP_DEAD.  (Fixed places: the workers share no counter for them.)
                 const uint64_t c3 = tick();
-                if (hits)
-                    spec_hits.fetch_add(hits, std::memory_order_relaxed);
-                if (deep)
-                    deep_hits.fetch_add(deep, std::memory_order_relaxed);
-                if (ahead)
-                    ahead_hits.fetch_add(ahead, std::memory_order_relaxed);
-                if (trace_on)
-                    ahead_sent.fetch_add(n_ahead_sent, std::memory_order_relaxed), open_sent.fetch_add(n_open_sent, std::memory_order_relaxed);
-                // This worker's nodes go into a range of the launch it claims in one step, copied by the thread
-                // that has just written them (one thread gathering everybody's nodes would fetch each line from
-                // another core's cache).  The order of the nodes within a launch is immaterial: results are found
-                // through slot0.
-                uint32_t mine = 0;
-                for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
-                    if (wants[g.live[k]])
-                        mine += (uint32_t)Q[g.live[k]].nspec;
-                uint32_t at = mine ? g.claim.fetch_add(mine, std::memory_order_relaxed) : 0;
-                for (size_t k = g.bounds[w]; k < g.bounds[w + 1]; ++k)
+                for (size_t k = k0; k < k1; ++k)
                 {
                     const uint32_t qi = g.live[k];
-                    if (!wants[qi])
-                        continue;
-                    slot0[qi] = at;
-                    for (int i = 0; i < Q[qi].nspec; ++i)
-                        r_in[g.base + at++] = stage[qi * KS + i];
+                    const size_t at = k * r_nodes;
+                    const size_t used = wants[qi] ? (size_t)Q[qi].nspec : 0;
+                    slot0[qi] = (uint32_t)at;
+                    StepIn *dst = r_in + (g.part_no & 1u) * nodes_max + g.base + at;
+                    for (size_t i = 0; i < used; ++i)
+                        dst[i] = stage[qi * KS + i];
+                    for (size_t i = used; i < r_nodes; ++i)
+                        dst[i] = StepIn{0.f, 0.f, 0.f, 0.f, 0, qi, STEP_DEAD, 0};
                 }
-                // the filter's updates likewise; what does not fit is left out (a bound that stays too high drops less)
-                if (my_upd.n)
-                {
-                    const uint32_t have = my_upd.n, u0 = g.upd_claim.fetch_add(have, std::memory_order_relaxed);
-                    const size_t room = u0 < g.upd_cap ? g.upd_cap - u0 : 0, take_n = std::min<size_t>(have, room);
-                    CellUpd *dst = r_upd + g.upd_base + u0;
-                    for (size_t i = 0; i < take_n; ++i)
-                        dst[i] = my_upd.p[i];
-                }
-                if (c->d_nodes && (mine || my_upd.n))
-                    __builtin_ia32_sfence(); // stores into device memory leave this core's write-combining buffers
+                Tally &tl = tally[w];
+                tl.hits += hits, tl.deep += deep, tl.ahead += ahead;
                 if (trace_on)
                 {
-                    cyc_consume.fetch_add(c_consume, std::memory_order_relaxed), cyc_advance.fetch_add(c_advance, std::memory_order_relaxed);
-                    cyc_next.fetch_add(c_next, std::memory_order_relaxed), cyc_copy.fetch_add(tick() - c3, std::memory_order_relaxed);
-                    pr_dup.fetch_add(t_probe.dup), pr_cell.fetch_add(t_probe.cell), pr_push.fetch_add(t_probe.push), pr_chain.fetch_add(t_probe.chain);
-                    pr_heads.fetch_add(t_probe.heads), pr_succ.fetch_add(t_probe.succ), pr_pushed.fetch_add(t_probe.pushed);
-                    pr_closed.fetch_add(t_probe.drop_closed), pr_worse.fetch_add(t_probe.drop_worse), pr_tie.fetch_add(t_probe.drop_tie);
-                    pr_dupdrop.fetch_add(t_probe.drop_dup);
-                    t_probe = ConsumeProbe();
+                    tl.ahead_sent += n_ahead_sent, tl.open_sent += n_open_sent;
+                    tl.c_consume += c_consume, tl.c_advance += c_advance, tl.c_next += c_next, tl.c_copy += tick() - c3;
                 }
-            });
+            }
+        };
+        // what the worker that finishes a host part last does before it launches: queries that finished drop out
+        auto end_host_part = [&](Group &g) -> bool {
+            g.ns = g.live.size() * g.r_nodes; // every query that was alive at the release has its slots in the launch
             g.keep.clear();
             for (uint32_t qi : g.live)
                 if (wants[qi])
                     g.keep.push_back(qi);
-            g.live.swap(g.keep); // queries that finished drop out
-            g.ns = g.claim.load(std::memory_order_relaxed);
+            g.live.swap(g.keep);
+            if (g.live.empty())
+                g.ns = 0;
             g.n_upd = std::min<size_t>(g.upd_claim.load(std::memory_order_relaxed), g.upd_cap);
-            g.t_host += now() - t0;
             return g.ns != 0;
         };
         // One launch per round.  The kernel reads the popped nodes from, and writes its results to, the pinned
@@ -1490,63 +1571,56 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             hipEvent_t *ev = c->round_ev[gi];
             const size_t s0 = g.base, ns = g.ns;
             const double t0 = now();
-            g.t_sub = t0;
-            if (g.t_done > 0)
-                g.t_idle += t0 - g.t_done;
             if (c->d_nodes)
                 __builtin_ia32_sfence(); // the stores into device memory leave the write-combining buffers before the doorbell
-            g.timed = ev_every > 0 && g.rounds % ev_every == 0;
+            // Kernel time: the group's pair of events goes round every second launch at most.  The pair recorded two
+            // launches ago is read first: this launch follows a host part that read answers of the launch before it,
+            // so the one before that has finished.
+            if (g.timed)
+            {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess)
+                    g.k_ms += ms, g.timed_launches += (int64_t)DEPTH;
+                else
+                    (void)hipGetLastError();
+            }
+            g.timed = ev_every > 0 && g.rounds % (2 * ev_every) == 0;
             g.rounds += 1;
             if (g.timed)
                 (void)hipEventRecord(ev[0], st);
+            const size_t par = g.part_no & 1u; // which set of node slots and cell updates this host part has filled
             for (size_t l = 0; l < DEPTH; ++l)
             {
-                size_t p_succ, p_len, p_ok, p_cnt;
-                slice(g, l, p_succ, p_len, p_ok, p_cnt);
-                const StepIn *d_in = l == 0 ? k_in + s0 : (const StepIn *)(ds + o_child + (l - 1) * child_stride) + s0;
+                const StepIn *d_in = l == 0 ? k_in + par * nodes_max + s0 : (const StepIn *)(ds + o_child + (l - 1) * child_stride) + s0;
                 StepIn *d_child = l + 1 < DEPTH ? (StepIn *)(ds + o_child + l * child_stride) + s0 : nullptr;
                 // the first launch of a round brings the cell bounds up to date, every launch tests against them
-                const CellFilter filter{filter_on ? c->d_bound : nullptr, (uint32_t)cells3d, k_upd + g.upd_base, l == 0 ? (uint32_t)g.n_upd : 0u};
-                launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, (uint8_t *)(hd + p_ok),
-                             (float *)(hd + p_len), (uint8_t *)(hd + p_cnt), (hyas_succ *)(hd + p_succ), c->stats_on ? c->d_stats : nullptr,
-                             c->stats_mode, st, d_child, P_analytic, filter);
+                const CellFilter filter{filter_on ? c->d_bound : nullptr, (uint32_t)cells3d, k_upd + par * upd_max + g.upd_base, l == 0 ? (uint32_t)g.n_upd : 0u};
+                const RoundOut out{(uint4 *)(hd + out_offset(g, l)), (uint32_t)out_units, g.part_no};
+                launch_round(m, d_in, (uint32_t)ns, (const hyas_goal *)(ds + o_goal), d_twod_cur, c->d_seg, c->seg_cap, nullptr, nullptr, nullptr, nullptr,
+                             c->stats_on ? c->d_stats : nullptr, c->stats_mode, st, d_child, P_analytic, filter, out);
             }
             if (g.timed)
                 (void)hipEventRecord(ev[1], st);
             hipError_t e = hipGetLastError();
+            g.launches += (int64_t)DEPTH;
             g.t_launch += now() - t0;
             return e == hipSuccess ? HYAS_OK : HYAS_ENODEV;
         };
-        auto wait = [&](Group &g, int gi) -> int {
-            const double t0 = now();
-            hipError_t e = hipStreamSynchronize(c->round_stream[gi]);
-            g.t_wait += now() - t0;
-            if (e != hipSuccess)
-                return HYAS_ENODEV;
-            float ms = 0;
-            g.t_done = now();
-            if (g.timed && hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
-            {
-                g.k_ms += ms, g.timed_launches += (int64_t)DEPTH;
-                g.t_turn += (g.t_done - g.t_sub) - (double)ms * 1e-3;
-            }
-            g.launches += (int64_t)DEPTH;
-            return HYAS_OK;
-        };
-        // One driver thread (with its helpers) takes every n_drivers-th group and keeps all of them in flight:
-        // while the kernel of one of its groups runs it does the host part of the next.
-        auto drive = [&](int d) {
+        std::atomic<bool> release_busy{false};
+        auto work = [&](int w) {
+            if (w >= nw)
+                return;
             if (hipSetDevice(c->device) != hipSuccess)
             {
-                G[d].rc = HYAS_ENODEV;
+                G[0].rc = HYAS_ENODEV;
+                abort_all.store(true, std::memory_order_release);
                 return;
             }
-            Pool &gp = *c->pools->driver[d];
             cpu_set_t before;
-            const bool pinned = c->pools->pinned && pthread_getaffinity_np(pthread_self(), sizeof before, &before) == 0;
+            const bool pinned = w == 0 && c->pools->round_pinned && pthread_getaffinity_np(pthread_self(), sizeof before, &before) == 0;
             if (pinned)
-                pin_self(d * gp.size(), c->pools->pin_total);
-            struct Unpin // the calling thread drives group 0: it gets its own mask back
+                pin_self(0, nw);
+            struct Unpin // the calling thread is worker 0: it gets its own mask back
             {
                 bool on;
                 cpu_set_t *set;
@@ -1556,48 +1630,134 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                         (void)pthread_setaffinity_np(pthread_self(), sizeof *set, set);
                 }
             } unpin{pinned, &before};
-            bool inflight[HYAS_MAX_GROUPS] = {false};
-            for (int gi = d; gi < ng; gi += n_drivers)
-                if (host_round(G[gi], gp, false))
-                {
-                    if ((G[gi].rc = launch(G[gi], gi)) != HYAS_OK)
-                        return;
-                    inflight[gi] = true;
-                }
-            for (bool any = true; any;)
+            uint64_t next = 0; // host parts this worker has done its share of
+            unsigned idle = 0;
+            t_probe = ConsumeProbe();
+            struct KeepProbe // what consume() counted on this thread goes to the worker's tally
             {
-                any = false;
-                for (int gi = d; gi < ng; gi += n_drivers)
+                ConsumeProbe &to;
+                ~KeepProbe() { to = t_probe; }
+            } keep_probe{tally[w].probe};
+            while (!abort_all.load(std::memory_order_acquire) && n_finished.load(std::memory_order_acquire) < ng)
+            {
+                if (released.load(std::memory_order_acquire) == next)
                 {
-                    if (!inflight[gi])
-                        continue;
-                    any = true;
-                    if ((G[gi].rc = wait(G[gi], gi)) != HYAS_OK)
-                        return;
-                    inflight[gi] = host_round(G[gi], gp, true);
-                    if (inflight[gi] && (G[gi].rc = launch(G[gi], gi)) != HYAS_OK)
-                        return;
+                    if (++idle > 20000) // more threads than free CPUs: let the others run
+                        std::this_thread::yield();
+                    else
+                        for (int i = 0; i < 4; ++i)
+                            __builtin_ia32_pause();
+                    continue;
+                }
+                idle = 0;
+                const uint64_t entry = order[next % ORDER_CAP].load(std::memory_order_relaxed);
+                const int gi = (int)(entry & 0xFFu);
+                const uint32_t part = (uint32_t)(entry >> 8);
+                ++next;
+                Group &g = G[gi];
+                // The pieces this worker gets hold of; what they change in the cell state goes into one list, handed in
+                // when no piece is left to take, and only then are the pieces reported as done: the worker whose report
+                // completes the host part finds everybody's nodes and cell changes in place.
+                UpdSink sink{filter_on ? g.upd[w].get() : nullptr, 0, filter_on ? (uint32_t)g.upd_cap : 0u};
+                uint32_t mine = 0;
+                uint64_t t_in = 0;
+                for (int k = 0; k < nw; ++k) // the home range first, then what is left of the others'
+                {
+                    Group::Cursor &cu = g.cur[(w + k) % nw];
+                    for (;;)
+                    {
+                        uint64_t v = cu.v.load(std::memory_order_acquire);
+                        const uint32_t nxt = (uint32_t)(v & 0xFFFFFu), end = (uint32_t)(v >> 20 & 0xFFFFFu);
+                        if ((uint32_t)(v >> 40) != part || nxt >= end)
+                            break;
+                        if (!cu.v.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel))
+                            continue;
+                        if (trace_on && !mine)
+                            t_in = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                        host_piece(g, w, (size_t)nxt * PIECE, std::min(g.live.size(), ((size_t)nxt + 1) * PIECE), filter_on ? &sink : nullptr);
+                        ++mine;
+                    }
+                }
+                if (!mine)
+                    continue;
+                if (sink.n)
+                {
+                    const uint32_t u0 = g.upd_claim.fetch_add(sink.n, std::memory_order_relaxed);
+                    const size_t room = u0 < g.upd_cap ? g.upd_cap - u0 : 0, take_n = std::min<size_t>(sink.n, room);
+                    CellUpd *dst = r_upd + (g.part_no & 1u) * upd_max + g.upd_base + u0;
+                    for (size_t i = 0; i < take_n; ++i)
+                        dst[i] = sink.p[i];
+                }
+                if (c->d_nodes)
+                    __builtin_ia32_sfence(); // stores into device memory leave this core's write-combining buffers
+                if (trace_on)
+                {
+                    const uint64_t t_out = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                    g.host_ns.fetch_add(t_out - t_in, std::memory_order_relaxed);
+                    uint64_t v = g.first_ns.load();
+                    while (t_in < v && !g.first_ns.compare_exchange_weak(v, t_in))
+                        ;
+                    v = g.last_ns.load();
+                    while (t_out > v && !g.last_ns.compare_exchange_weak(v, t_out))
+                        ;
+                }
+                if (g.pieces_left.fetch_sub(mine, std::memory_order_acq_rel) != mine)
+                    continue;
+                if (!end_host_part(g))
+                {
+                    g.state.store(G_FINISHED, std::memory_order_release);
+                    n_finished.fetch_add(1, std::memory_order_acq_rel);
+                }
+                else if ((g.rc = launch(g, gi)) != HYAS_OK)
+                    abort_all.store(true, std::memory_order_release);
+                else
+                {
+                    // The answers are read as they arrive: the group's next host part is released right away, behind
+                    // the host parts of the launches that left before this one.
+                    while (release_busy.exchange(true, std::memory_order_acquire))
+                        __builtin_ia32_pause();
+                    begin_host_part(g, true);
+                    release_busy.store(false, std::memory_order_release);
                 }
             }
         };
         const double wall_setup = cur.t_all;
-        c->pools->driver_pools(n_drivers, threads_per_driver);
+        Pool &round_pool = c->pools->round_pool(nw);
         if (filter_on)
         {
             // every cell of every query of the chunk unseen: +inf
             HYAS_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_bound, 0x7F800000, cn * cells3d, c->stream));
             HYAS_HIP(c, hipStreamSynchronize(c->stream));
         }
-        {
-            std::vector<std::thread> drivers;
-            for (int d = 1; d < n_drivers; ++d)
-                drivers.emplace_back(drive, d);
-            drive(0);
-            for (auto &t : drivers)
-                t.join();
-        }
+        std::memset(hs + o_succ, 0, (size_t)ng * DEPTH * res_stride(gslots)); // no unit carries a tag yet
+        for (int gi = 0; gi < ng; ++gi)
+            begin_host_part(G[gi], false);
+        round_pool.run_parts(work);
+        // the last launches may still be running (nodes whose answers the searches did not wait for)
+        for (int gi = 0; gi < ng; ++gi)
+            if (hipStreamSynchronize(c->round_stream[gi]) != hipSuccess && G[gi].rc == HYAS_OK)
+                G[gi].rc = HYAS_ENODEV;
+        for (int gi = 0; gi < ng; ++gi)
+            if (G[gi].timed)
+            {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, c->round_ev[gi][0], c->round_ev[gi][1]) == hipSuccess)
+                    G[gi].k_ms += ms, G[gi].timed_launches += (int64_t)DEPTH;
+                else
+                    (void)hipGetLastError();
+            }
         const double wall_rounds = since(wall0);
-        double t_host = 0, t_launch = 0, t_wait = 0;
+        Tally sum;
+        for (const Tally &tl : tally)
+        {
+            sum.hits += tl.hits, sum.deep += tl.deep, sum.ahead += tl.ahead, sum.ahead_sent += tl.ahead_sent, sum.open_sent += tl.open_sent;
+            sum.c_consume += tl.c_consume, sum.c_advance += tl.c_advance, sum.c_next += tl.c_next, sum.c_copy += tl.c_copy;
+            sum.probe.dup += tl.probe.dup, sum.probe.cell += tl.probe.cell, sum.probe.push += tl.probe.push, sum.probe.chain += tl.probe.chain;
+            sum.probe.heads += tl.probe.heads, sum.probe.succ += tl.probe.succ, sum.probe.pushed += tl.probe.pushed;
+            sum.probe.drop_closed += tl.probe.drop_closed, sum.probe.drop_worse += tl.probe.drop_worse, sum.probe.drop_tie += tl.probe.drop_tie;
+            sum.probe.drop_dup += tl.probe.drop_dup;
+        }
+        double t_host = 0, t_launch = 0;
         for (int gi = 0; gi < ng; ++gi)
         {
             if (G[gi].rc != HYAS_OK)
@@ -1605,20 +1765,20 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             // kernel time of all launches, from the ones that carried timing events
             if (G[gi].timed_launches > 0)
                 c->k_ms[0] += G[gi].k_ms * (double)G[gi].launches / (double)G[gi].timed_launches, c->k_launches[0] += G[gi].launches;
-            t_host = std::max(t_host, G[gi].t_host), t_launch = std::max(t_launch, G[gi].t_launch), t_wait = std::max(t_wait, G[gi].t_wait);
+            t_host += (double)G[gi].host_ns.load() * 1e-9, t_launch += G[gi].t_launch;
         }
 
         if (trace_on)
             fprintf(stderr, "hyas rounds ended by: a successor of a node of the same round %llu, an older open-list entry %llu; answered ahead: "
                             "open-list entries %llu of %llu sent, nodes sent ahead of their existence %llu of %llu (at most %d per query), successors expanded "
                             "by the deeper launches %llu (%d launches per round)\n",
-                    (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)spec_hits.load(),
-                    (unsigned long long)open_sent.load(), (unsigned long long)ahead_hits.load(), (unsigned long long)ahead_sent.load(), ahead_cfg,
-                    (unsigned long long)deep_hits.load(), depth_cfg);
+                    (unsigned long long)miss_child.load(), (unsigned long long)miss_other.load(), (unsigned long long)sum.hits,
+                    (unsigned long long)sum.open_sent, (unsigned long long)sum.ahead, (unsigned long long)sum.ahead_sent, ahead_cfg,
+                    (unsigned long long)sum.deep, depth_cfg);
         if (trace_on)
             fprintf(stderr, "hyas host threads, timestamp-counter cycles in all: taking successors %.3e, popping %.3e, choosing and staging the next nodes %.3e, "
                             "copying them into the launch %.3e\n",
-                    (double)cyc_consume.load(), (double)cyc_advance.load(), (double)cyc_next.load(), (double)cyc_copy.load());
+                    (double)sum.c_consume, (double)sum.c_advance, (double)sum.c_next, (double)sum.c_copy);
         if (trace_on)
             for (int a = 0; a < 2; ++a)
                 for (int pp = 0; pp < 8; ++pp)
@@ -1636,23 +1796,26 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         if (trace_on)
             fprintf(stderr, "hyas taking successors: %.3e successors, duplicate check %.3e cycles (%.3e occupied buckets, %.3e open-list entries compared), "
                             "cell lookup %.3e cycles, %.3e pushes %.3e cycles\n",
-                    (double)pr_succ.load(), (double)pr_dup.load(), (double)pr_heads.load(), (double)pr_chain.load(), (double)pr_cell.load(),
-                    (double)pr_pushed.load(), (double)pr_push.load());
+                    (double)sum.probe.succ, (double)sum.probe.dup, (double)sum.probe.heads, (double)sum.probe.chain, (double)sum.probe.cell,
+                    (double)sum.probe.pushed, (double)sum.probe.push);
         if (trace_on)
             fprintf(stderr, "hyas successors dropped: cell closed %.3e, cell open with a cost not worse %.3e, same cell beyond the tie breaker %.3e, "
                             "duplicate of an open-list entry %.3e\n",
-                    (double)pr_closed.load(), (double)pr_worse.load(), (double)pr_tie.load(), (double)pr_dupdrop.load());
+                    (double)sum.probe.drop_closed, (double)sum.probe.drop_worse, (double)sum.probe.drop_tie, (double)sum.probe.drop_dup);
         if (trace_on)
             for (int gi = 0; gi < ng; ++gi)
-                fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host %.3f s launch %.3f s wait %.3f s\n",
+                fprintf(stderr, "hyas group %d host parts, from release: first worker begins after %.1f us, last worker ends after %.1f us\n", gi,
+                        G[gi].sum_first * 1e-3 / std::max<uint64_t>(G[gi].parts, 1), G[gi].sum_last * 1e-3 / std::max<uint64_t>(G[gi].parts, 1));
+        if (trace_on)
+            for (int gi = 0; gi < ng; ++gi)
+                fprintf(stderr, "hyas group %d: %lld launches, kernel %.1f us, submit-to-seen minus kernel %.1f us, seen-to-next-submit %.1f us, host parts %.3f thread-s, launch %.3f s\n",
                         gi, (long long)G[gi].launches, G[gi].k_ms * 1e3 / std::max<int64_t>(G[gi].timed_launches, 1), G[gi].t_turn * 1e6 / std::max<int64_t>(G[gi].timed_launches / (int64_t)DEPTH, 1),
-                        G[gi].t_idle * 1e6 / std::max<int64_t>(G[gi].launches, 1), G[gi].t_host, G[gi].t_launch, G[gi].t_wait);
+                        G[gi].t_idle * 1e6 / std::max<int64_t>(G[gi].launches, 1), (double)G[gi].host_ns.load() * 1e-9, G[gi].t_launch);
         if (trace_on)
             fprintf(stderr,
-                    "hyas rounds (%d groups, %d drivers x %d threads, %d nodes per query; slowest group): host push+pop %.3f s, launch %.3f s, "
-                    "wait %.3f s; %llu expansions answered ahead of time; wall: set-up %.3f s (pose checks + 2D floods %.3f s), rounds %.3f s\n",
-                    ng, n_drivers, threads_per_driver, spec_k, t_host, t_launch, t_wait, (unsigned long long)spec_hits.load(), wall_setup,
-                    wall_flood, wall_rounds);
+                    "hyas rounds (%d groups, %d worker threads, %d nodes per query): host parts %.3f thread-s of %.3f, launches %.3f thread-s; "
+                    "%llu expansions answered ahead of time; wall: set-up %.3f s (pose checks + 2D floods %.3f s), rounds %.3f s\n",
+                    ng, nw, spec_k, t_host, wall_rounds * nw, t_launch, (unsigned long long)sum.hits, wall_setup, wall_flood, wall_rounds);
         // paths back to the start (TracePath, :813-828), GetPath's RemoveDuplicates for the endings that have it in front
         // of ShortCut (:121, :138), then ShortCut itself (:122-125, :139-142, :165-168) for all of them in one launch
         {
