@@ -20,6 +20,7 @@
 #include <sched.h>
 
 #include "hyas_ctx.h"
+#include "hyas_open_list.h"
 
 namespace hyas
 {
@@ -42,16 +43,6 @@ struct SNode
     int32_t dup_prev; // >= 0 arena index, < 0: -(bucket + 2), head of its bucket
 };
 
-struct HeapItem
-{
-    float f;
-    uint32_t seq;
-    int32_t node;
-    int32_t idx; // the node's cell (Node3D::setIdx), as the kernel computed it: not recomputed at every look
-};
-// Open list order: lowest f = g + h first (CompareNodes, include/hybrid_a_star.h:31-43); equal f: earliest
-// push first.  (Boost's binomial heap leaves the order of equal keys unspecified.)  See Driver::before().
-
 // idx -> {g, open, closed}: the three Node3D fields GetPath reads back from
 // nodes3D[] (:101, :110, :264, :271).  Open addressing, grows at 50 % load.
 struct CellMap
@@ -71,6 +62,8 @@ struct CellMap
     }
     // Successors of a node fall into the same or neighbouring cells: keeping neighbouring keys in neighbouring
     // slots makes the lookups of one expansion share cache lines.  Keys are dense, so runs rarely collide.
+    // (Tried: the heading bins of one position side by side in windows of 128 slots, positions scattered over the
+    // windows.  Slower: a search visits few positions with many headings each, and the windows fill up unevenly.)
     static size_t hash(int32_t k) { return (size_t)(uint32_t)k; }
     Slot *find(int32_t key)
     {
@@ -116,7 +109,7 @@ struct Query
     SNode start;
     uint32_t dist_start_goal_bits = 0; // bits of the float GetDistance(start, goal), for the adaptive steering selection
     std::vector<SNode> arena;
-    std::vector<HeapItem> heap;
+    OpenList open;
     uint32_t seq = 0;
     CellMap cells;
     std::vector<int32_t> dup_head; // spatial hash over the open list
@@ -168,6 +161,7 @@ struct ConsumeProbe
 {
     uint64_t dup = 0, cell = 0, push = 0, chain = 0, heads = 0, succ = 0, pushed = 0;
     uint64_t drop_closed = 0, drop_worse = 0, drop_tie = 0, drop_dup = 0; // successors dropped, by the test that dropped them
+    uint64_t waited = 0, waits = 0; // cycles spent waiting for answer units that had not arrived, and how often
 };
 static thread_local ConsumeProbe t_probe;
 
@@ -187,10 +181,12 @@ struct Driver
     // through the reference's own comparison, so the answer is the linear
     // scan's answer.
     static int32_t bucket_coord(float v) { return (int32_t)std::floor((double)v * 10.0); }
-    // buckets of one row are adjacent in memory: the 3x3 neighbourhood of a lookup touches three short runs
+    // buckets in tiles of 4 x 4 (0.4 m x 0.4 m, one cache line of bucket heads): a lookup's neighbourhood touches one or
+    // two lines, and so do the lookups of the next expansions, which are a step of 0.2 m further on
     static size_t bucket_hash(int32_t bx, int32_t by, size_t mask)
     {
-        return (size_t)((uint32_t)by * 2654435761u + (uint32_t)bx) & mask;
+        const uint32_t tile = ((uint32_t)(by >> 2) * 2654435761u + (uint32_t)(bx >> 2)) * 0x9E3779B1u >> 4;
+        return (size_t)(tile << 4 | (uint32_t)(by & 3) << 2 | (uint32_t)(bx & 3)) & mask;
     }
     void dup_link(Query &q, int32_t id)
     {
@@ -204,13 +200,14 @@ struct Driver
     }
     void dup_insert(Query &q, int32_t id)
     {
-        if (q.heap.size() > q.dup_head.size())
+        if (q.open.size() > q.dup_head.size())
         {
-            // rebuild with four times the buckets; the heap holds the live set
+            // rebuild with four times the buckets; the open list holds the live set
             q.dup_head.assign(q.dup_head.size() * 4, -1);
-            for (const HeapItem &e : q.heap)
+            q.open.for_each([&](const HeapItem &e) {
                 if (e.node != id)
                     dup_link(q, e.node);
+            });
         }
         dup_link(q, id);
     }
@@ -261,54 +258,40 @@ struct Driver
         return false;
     }
 
-    // ---- heap ------------------------------------------------------------
-    // Binary min-heap on (f, seq), a strict total order: the pop sequence does not depend on the heap's shape.
-    struct After
-    {
-        bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f > b.f || (a.f == b.f && a.seq > b.seq); }
-    };
+    // ---- open list -------------------------------------------------------
     void push(Query &q, const SNode &n, int32_t idx)
     {
         q.arena.push_back(n);
         int32_t id = (int32_t)q.arena.size() - 1;
-        q.heap.push_back(HeapItem{n.g + n.h, q.seq++, id, idx}); // getTotalCost(), include/node3d.h:36
-        std::push_heap(q.heap.begin(), q.heap.end(), After());
+        q.open.push(HeapItem{n.g + n.h, q.seq++, id, idx}); // getTotalCost(), include/node3d.h:36
         dup_insert(q, id);
     }
     void pop(Query &q)
     {
-        dup_remove(q, q.heap.front().node);
-        std::pop_heap(q.heap.begin(), q.heap.end(), After());
-        q.heap.pop_back();
+        dup_remove(q, q.open.top().node);
+        q.open.pop();
     }
 
-    // The open list's next best entries after its top, at most `want` of them, in pop order; entries whose cell
-    // is already closed are passed over (advance() would discard them).  Does not modify the heap.
+    // The open list's best entries, at most `want` of them, in pop order; entries whose cell is already closed are passed
+    // over (advance() would discard them).  Pops nothing (entries may move from the heap into the sorted array).
     int next_best(Query &q, int32_t *out, int want) const
     {
-        const std::vector<HeapItem> &h = q.heap;
-        After after;
-        size_t cand[2 * HYAS_MAX_SPEC + 4];
-        int nc = 0, got = 0;
-        if (!h.empty())
-            cand[nc++] = 0; // the current top: it is popped next if cur's successors do not beat it
-        // the heap array is a binary tree: the next smallest entry is always a child of one already taken
-        int guard = 4 * HYAS_MAX_SPEC;
-        while (nc > 0 && got < want && guard-- > 0)
+        OpenList &o = q.open;
+        int got = 0, looked = 0;
+        const int look = std::min(OpenList::HOT, 2 * want + 2); // how far down the list to look for them
+        if (o.nh < look)
+            o.refill(look - o.nh);
+        const size_t cmask = q.cells.slots.size() - 1;
+        // (the lines the following steps read are requested as soon as their addresses are known)
+        for (int i = o.nh - 1, n = 0; i >= 0 && n < look; --i, ++n)
+            __builtin_prefetch(&q.cells.slots[q.cells.hash(o.hot[i].idx) & cmask]);
+        for (int i = o.nh - 1; i >= 0 && got < want && looked < look; --i, ++looked)
         {
-            int b = 0;
-            for (int i = 1; i < nc; ++i)
-                if (after(h[cand[b]], h[cand[i]]))
-                    b = i;
-            const size_t at = cand[b];
-            cand[b] = cand[--nc];
-            CellMap::Slot *cell = q.cells.find(h[at].idx);
-            if (!(cell && cell->closed))
-                out[got++] = h[at].node;
-            if (2 * at + 1 < h.size() && nc < (int)(sizeof cand / sizeof cand[0]))
-                cand[nc++] = 2 * at + 1;
-            if (2 * at + 2 < h.size() && nc < (int)(sizeof cand / sizeof cand[0]))
-                cand[nc++] = 2 * at + 2;
+            CellMap::Slot *cell = q.cells.find(o.hot[i].idx);
+            if (cell && cell->closed)
+                continue;
+            out[got++] = o.hot[i].node;
+            __builtin_prefetch(&q.arena[o.hot[i].node]);
         }
         return got;
     }
@@ -398,12 +381,12 @@ struct Driver
     static constexpr int32_t CLOSED_BITS = (int32_t)0xFF800000u; // -inf
     bool advance(Query &q, UpdSink *upd = nullptr)
     {
-        while (!q.heap.empty())
+        while (!q.open.empty())
         {
-            const int32_t pid = q.heap.front().node;
+            const int32_t pid = q.open.top().node;
             q.res.nodes_explored++;
             const SNode &n = q.arena[pid];
-            const int32_t iPred = q.heap.front().idx;
+            const int32_t iPred = q.open.top().idx;
             q.iterations++;
             CellMap::Slot &cell = q.cells.get(iPred);
             if (cell.closed)
@@ -492,7 +475,7 @@ struct Driver
             for (int k = 0; k < count; ++k)
             {
                 const hyas_succ &s = succ[k];
-                __builtin_prefetch(&q.cells.slots[CellMap::hash(s.idx) & cmask]);
+                __builtin_prefetch(&q.cells.slots[q.cells.hash(s.idx) & cmask]);
             }
         }
         // the successor the kernel has sent on to the next, deeper launch of this round (marked pad = 1)
@@ -1216,11 +1199,18 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             }
         };
         auto unit = [&](const char *p, uint32_t tag, int shift, uint32_t w[4]) -> bool {
+            uint64_t wait0 = 0;
             for (uint64_t spins = 0;; ++spins)
             {
                 _mm_storeu_si128((__m128i *)w, _mm_load_si128((const __m128i *)p));
                 if (((w[3] >> shift) & ROUND_TAG_MASK) == tag)
+                {
+                    if (spins && trace_on)
+                        t_probe.waited += __builtin_ia32_rdtsc() - wait0, t_probe.waits += 1;
                     return true;
+                }
+                if (!spins && trace_on)
+                    wait0 = __builtin_ia32_rdtsc();
                 __builtin_ia32_pause();
                 if ((spins & 0xFFFFF) == 0xFFFFF) // a launch that does not come back: ask the runtime what happened to it
                 {
@@ -1300,8 +1290,34 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 const uint32_t read_tag = g.read_tag;
                 uint64_t hits = 0, deep = 0, ahead = 0, n_ahead_sent = 0, n_open_sent = 0, c_consume = 0, c_advance = 0, c_next = 0;
                 const size_t r_nodes = g.r_nodes;
+                // Nearly every line a query touches is cold (a worker sees it once per round, between dozens of other
+                // queries): what can be known ahead is requested ahead.  First the queries' own records ...
                 for (size_t k = k0; k < k1; ++k)
                 {
+                    const char *qp = (const char *)&Q[g.live[k]];
+                    __builtin_prefetch(qp), __builtin_prefetch(qp + 64), __builtin_prefetch(qp + 128), __builtin_prefetch(qp + 192);
+                }
+                // ... then, one query ahead of the one being worked on: the head of every answer block it may read, the
+                // top of its open list and its node of this round
+                auto warm = [&](size_t k) {
+                    const Query &nq = Q[g.live[k]];
+                    if (have_results)
+                    {
+                        const char *blk = g.out[0] + (size_t)slot0[g.live[k]] * out_units * 16;
+                        for (int i = 0; i < nq.nspec; ++i)
+                            __builtin_prefetch(blk + (size_t)i * out_units * 16);
+                        if (nq.cur >= 0)
+                            __builtin_prefetch(&nq.arena[nq.cur]);
+                    }
+                    if (!nq.open.empty())
+                        __builtin_prefetch(&nq.open.hot[nq.open.nh - 1]), __builtin_prefetch(&nq.open.hot[std::max(0, nq.open.nh - 5)]);
+                };
+                if (k0 < k1)
+                    warm(k0);
+                for (size_t k = k0; k < k1; ++k)
+                {
+                    if (k + 1 < k1)
+                        warm(k + 1);
                     Query &q = Q[g.live[k]];
                     const uint32_t qi = g.live[k];
                     bool want;
@@ -1755,7 +1771,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             sum.probe.dup += tl.probe.dup, sum.probe.cell += tl.probe.cell, sum.probe.push += tl.probe.push, sum.probe.chain += tl.probe.chain;
             sum.probe.heads += tl.probe.heads, sum.probe.succ += tl.probe.succ, sum.probe.pushed += tl.probe.pushed;
             sum.probe.drop_closed += tl.probe.drop_closed, sum.probe.drop_worse += tl.probe.drop_worse, sum.probe.drop_tie += tl.probe.drop_tie;
-            sum.probe.drop_dup += tl.probe.drop_dup;
+            sum.probe.drop_dup += tl.probe.drop_dup, sum.probe.waited += tl.probe.waited, sum.probe.waits += tl.probe.waits;
         }
         double t_host = 0, t_launch = 0;
         for (int gi = 0; gi < ng; ++gi)
@@ -1798,6 +1814,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             "cell lookup %.3e cycles, %.3e pushes %.3e cycles\n",
                     (double)sum.probe.succ, (double)sum.probe.dup, (double)sum.probe.heads, (double)sum.probe.chain, (double)sum.probe.cell,
                     (double)sum.probe.pushed, (double)sum.probe.push);
+        if (trace_on)
+            fprintf(stderr, "hyas answers waited for: %.3e times, %.3e cycles in all\n", (double)sum.probe.waits, (double)sum.probe.waited);
         if (trace_on)
             fprintf(stderr, "hyas successors dropped: cell closed %.3e, cell open with a cost not worse %.3e, same cell beyond the tie breaker %.3e, "
                             "duplicate of an open-list entry %.3e\n",

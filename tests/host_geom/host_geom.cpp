@@ -12,7 +12,9 @@
 #include "../../path_planner_amd/csrc/hyas_flood.h"
 #include "../../path_planner_amd/csrc/hyas_bezier.h"
 #include "../../path_planner_amd/csrc/hyas_adaptive.h"
+#include "../../path_planner_amd/csrc/hyas_open_list.h"
 #include <queue>
+#include <set>
 
 using namespace hyas;
 
@@ -190,6 +192,57 @@ struct RefCmp
 {
     bool operator()(const std::pair<int, double> &l, const std::pair<int, double> &r) const { return l.second >= r.second; }
 };
+// The search's open list (sorted front array + heap) against an ordered set under the same (f, seq) order: a mix of
+// pushes, pops and look-aheads (which move entries from the heap into the array); returns the number of pops whose node
+// differs plus the number of steps after which size or emptiness differ.
+extern "C" long hg_open_list_mismatches(const float *f, const uint8_t *op, int n_ops)
+{
+    OpenList o;
+    struct Less
+    {
+        bool operator()(const HeapItem &a, const HeapItem &b) const { return a.f < b.f || (a.f == b.f && a.seq < b.seq); }
+    };
+    std::set<HeapItem, Less> ref;
+    long bad = 0;
+    uint32_t seq = 0;
+    for (int i = 0; i < n_ops; i++)
+    {
+        if (op[i] == 1) // pop
+        {
+            if (ref.empty())
+            {
+                bad += o.empty() ? 0 : 1;
+                continue;
+            }
+            if (o.empty() || o.top().node != ref.begin()->node)
+                ++bad;
+            if (!o.empty())
+                o.pop();
+            ref.erase(ref.begin());
+        }
+        else if (op[i] == 2) // look ahead: the array must then hold the list's best entries, best last
+        {
+            o.refill(11);
+            auto it = ref.begin();
+            for (int k = o.nh - 1; k >= 0; --k, ++it)
+                if (it == ref.end() || it->node != o.hot[k].node)
+                {
+                    ++bad;
+                    break;
+                }
+        }
+        else
+        {
+            const HeapItem e{f[i], seq, (int32_t)seq, i};
+            ++seq;
+            o.push(e);
+            ref.insert(e);
+        }
+        bad += (o.size() != ref.size()) + (o.empty() != ref.empty());
+    }
+    return bad;
+}
+
 extern "C" long hg_heap_mismatches(const float *prio, const uint8_t *is_pop, int n_ops)
 {
     VecHeap h;

@@ -24,7 +24,8 @@ def host_geom():
     so, src = HG / "libhost_geom.so", HG / "host_geom.cpp"
     deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h",
             ROOT / "path_planner_amd/csrc/hyas_rs.h", ROOT / "path_planner_amd/csrc/hyas_flood.h",
-            ROOT / "path_planner_amd/csrc/hyas_bezier.h", ROOT / "path_planner_amd/csrc/hyas_adaptive.h"]
+            ROOT / "path_planner_amd/csrc/hyas_bezier.h", ROOT / "path_planner_amd/csrc/hyas_adaptive.h",
+            ROOT / "path_planner_amd/csrc/hyas_open_list.h"]
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
                         "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
@@ -100,6 +101,20 @@ def test_side_by_side_reeds_shepp_candidates_equal_the_plain_form(host_geom):
     x = np.concatenate([rng.uniform(-100, 100, 200000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, math.pi / 4, -math.pi / 4, 1e5, -1e5]])
     host_geom.hg_sincos_mismatches.restype = C.c_long
     assert host_geom.hg_sincos_mismatches(np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), len(x)) == 0
+
+
+def test_open_list_pops_in_cost_then_push_order(host_geom):
+    """The search's open list (a sorted array of the best entries in front of a binary heap) must pop exactly like any
+    container ordered by (f, push order): mixes of pushes, pops and look-aheads with few and with many distinct costs,
+    rising costs (a search moving away from its start) and falling ones."""
+    rng = np.random.default_rng(11)
+    host_geom.hg_open_list_mismatches.restype = C.c_long
+    for n, levels, p_pop, trend in ((3000, 3, 0.45, 0.0), (60000, 50, 0.3, 0.0), (60000, 100000, 0.48, 1e-3), (60000, 1000, 0.2, -1e-3),
+                                    (500, 1, 0.5, 0.0), (40000, 7, 0.6, 0.0)):
+        f = np.ascontiguousarray((rng.integers(0, levels, n) * 0.25 + trend * np.arange(n)).astype(np.float32))
+        u = rng.random(n)
+        op = np.ascontiguousarray(np.where(u < p_pop, 1, np.where(u < p_pop + 0.05, 2, 0)).astype(np.uint8))
+        assert host_geom.hg_open_list_mismatches(f.ctypes.data_as(C.c_void_p), op.ctypes.data_as(C.c_void_p), n) == 0
 
 
 def test_flood_queue_pops_like_the_reference_priority_queue(host_geom):
