@@ -144,6 +144,8 @@ def dry_run(args):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("HYAS_DRY_RUN_FAIL_RANK") == str(rank):  # launcher test: one rank dies before the rendezvous
+        raise SystemExit(3)
     if world > 1:
         dist.init_process_group("gloo")
     b, e = query_shard(args.queries, rank, world) if (args.scaling or "weak") == "strong" else (0, args.queries)
@@ -204,7 +206,7 @@ def main():
             dist.init_process_group(backend)
 
     from path_planner_amd import Hyas, hot_path_params
-    from path_planner_amd.sharding import aggregate, load_map, make_queries, query_shard
+    from path_planner_amd.sharding import aggregate, load_map, make_queries, query_shard, result_digest
 
     scaling = args.scaling or "weak"
     map_arr = load_map("map_maze")
@@ -229,17 +231,24 @@ def main():
     for _ in range(args.warmup):
         ctx.plan_batch(starts, goals)
 
+    # the timed steps carry no timing events (they lengthen every launch call); the kernel's duration is taken in an
+    # untimed pass of the same batch below
+    ctx.set_round_timing(0)
     barrier()
-    kern_ms = 0.0
-    kern_launches = 0
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         res = ctx.plan_batch(starts, goals)
-        ms, nl = ctx.kernel_ms(0)  # HIP events on the streams the round kernel is launched on, summed over launches
-        kern_ms += ms
-        kern_launches += nl
+        step_s.append(time.perf_counter() - t_step)
     barrier()
     local_s = time.perf_counter() - t0
+    # untimed: the same batch once more with HIP events round the launches (every second launch of a query group,
+    # on the stream it is launched on; the sum is scaled to all launches)
+    ctx.set_round_timing(1)
+    ctx.plan_batch(starts, goals)
+    kern_ms, kern_launches = ctx.kernel_ms(0)
+    ctx.set_round_timing(0)
 
     succ = float(res["successors"].sum()) * args.steps
     expd = float(res["nodes_expanded"].sum()) * args.steps
@@ -266,10 +275,13 @@ def main():
         avg_ms = kern_ms / max(kern_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
-        # HBM-side bytes per launch from the rocprofv3 counter passes (profiles/collect_traffic.sh), newest file
+        traffic_source = None
+        # HBM-side bytes per launch from the rocprofv3 counter passes (profiles/collect_traffic.sh), newest file: taken
+        # on the builder's box with a shorter workload (300 iterations per query), not in this run
         for tf in sorted((ROOT / "profiles").glob("r*_step_kernel_traffic.json"), reverse=True):
             try:
                 traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/{tf.name}: counter passes of an earlier run (1024 maze queries, 300 iterations each), not of this one"
                 break
             except Exception:
                 traffic = None
@@ -280,14 +292,17 @@ def main():
                 d = json.loads(lf.read_text())
                 l2 = {k: d[k] for k in ("l2_requests_per_launch", "l2_hit_rate", "l2_GBps_at_64B_per_request",
                                         "l2_GBps_at_128B_per_request", "l2_peak_GBps")}
-                l2["source"] = f"profiles/{lf.name}"
+                l2["source"] = f"profiles/{lf.name}: counter passes of an earlier run (1024 maze queries, 300 iterations each), not of this one"
                 break
             except Exception:
                 l2 = None
         frac = achieved / HBM_PEAK_GBS
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                     "useful_frac": frac * consumed / max(st["nodes"], 1),
-                    "traffic": traffic, "kernel": "k_round", "avg_launch_us": avg_ms * 1e3,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "moved_bytes_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
+                    "kernel": "k_round", "avg_launch_us": avg_ms * 1e3,
+                    "avg_launch_us_source": "HIP events on the launching streams in an untimed pass of the same batch (the timed steps carry no events)",
                     "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": launches_1, "l2": l2,
                     "note": "map, obstacle lists and tables are <= 30 MB and cache-resident: HBM and L2 fractions are low by "
                             "construction; a launch lasts as long as its slowest workgroup's dependent chain (solve, pick, "
@@ -303,6 +318,16 @@ def main():
             cpu_all = cpu_baseline_all_cores(map_arr, starts, goals)
 
     if rank == 0:
+        # what the timed steps answered; for the workload as defined (1024 queries, seed 20250228) the GPU test
+        # tests/test_gpu_fullsize.py::test_maze_1024_queries_properties compares every query of this very batch with
+        # the CPU oracle and pins the same digest in tests/golden/bench_digest.json
+        digest = result_digest(res)
+        verified = None
+        if args.queries == 1024 and (scaling == "weak" or world == 1):
+            try:
+                verified = digest == json.loads((ROOT / "tests" / "golden" / "bench_digest.json").read_text())["queries_maze"]
+            except Exception:
+                verified = None
         status = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
         per = "per GPU" if scaling == "weak" else f"in all, contiguous blocks over {world} GPU(s)"
         line = {
@@ -313,6 +338,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * total_s / args.steps,
+            "ms_per_step_median_rank0": 1e3 * float(np.median(step_s)),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -325,6 +351,8 @@ def main():
             "queries_per_s": nq / total_s,
             "nodes_expanded_per_s": expd / total_s,
             "status_counts_rank0": status,
+            "result_digest_rank0": digest,
+            "result_digest_verified": verified,
             "setup_s": setup_s,
             "table_build_ms": table_ms,
             "counters_rank0_one_step": counters,

@@ -81,7 +81,8 @@ typedef struct hyas_params
     int32_t steering_angle_towards_free_angle_range_for_obstacle_angle_range;    /* 1 */
     int32_t fixed_number_of_steering_angle_in_free_angle_range;                  /* 1 */
     float constant_density;           /* 0.5 */
-    int32_t piecewise_cubic_bezier_interpolation; /* 0 (only 0 is supported) */
+    int32_t piecewise_cubic_bezier_interpolation; /* 0; 1: the traced part of a path closed by an analytic shot is replaced by
+                                                   * cubic Bezier curves between its anchor nodes (src/hybrid_a_star.cpp:830-883) */
     float curve_step_size;            /* 1 */
     int32_t reserved;
 } hyas_params;
@@ -137,7 +138,12 @@ void hyas_default_params(hyas_params *p);
 void hyas_hot_path_params(hyas_params *p);
 
 /* replaces: HybridAStarPlanner ctor + parameter load,
- * src/hybrid_a_star_planner.cpp:17-35, :59.  device = HIP device ordinal. */
+ * src/hybrid_a_star_planner.cpp:17-35, :59.  device = HIP device ordinal.
+ * Side effect on the calling process: hyas_create calls
+ * setenv("HIP_FORCE_DEV_KERNARG", "1", overwrite = 0) before its first HIP call
+ * (kernel arguments in device memory: 2-3 us less per launch).  The HIP runtime
+ * reads the variable when it starts up, so the setting only takes effect in a
+ * process that has made no HIP call yet; a value the caller has set is kept. */
 hyas_ctx *hyas_create(const hyas_params *params, int device);
 void hyas_destroy(hyas_ctx *ctx);
 const char *hyas_last_error(const hyas_ctx *ctx);
@@ -176,6 +182,10 @@ int hyas_in_range_list(const hyas_ctx *ctx, uint32_t key, float *out, size_t cap
  * predecessor or NULL (pose test only); free_out[i] = 1 iff traversable. */
 int hyas_collision_batch(hyas_ctx *ctx, int mode, const float *xyt, const float *pred_xy,
                          size_t n, uint8_t *free_out);
+/* The same on DEVICE buffers.  Any alignment a float / byte array may have is
+ * accepted; mode FOOTPRINT runs its vectorised kernels when xyt_dev is 16-byte
+ * and free_out_dev 4-byte aligned (what hipMalloc and torch give) and a
+ * scalar-access kernel otherwise. */
 int hyas_collision_batch_dev(hyas_ctx *ctx, int mode, const float *xyt_dev,
                              const float *pred_xy_dev, size_t n, uint8_t *free_out_dev);
 
@@ -231,10 +241,11 @@ int hyas_table_build_dev(hyas_ctx *ctx, int curve, int slice_begin, int slice_en
 /* Applies the reference's first-write-wins emplace (src/lookup_table.cpp:176,
  * :215) of all nslices raw slices into the context's keyed table. */
 int hyas_table_install_dev(hyas_ctx *ctx, int curve, const float *raw_dev);
-/* hyas_table_install_dev for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc): the same first-write-wins install, with its per-key scratch (one loop rank per
+/* hyas_table_install_dev for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc
+ * once they are running): the same first-write-wins install, with its per-key scratch (one loop rank per
  * table key) in a static device array instead of a temporary allocation.  No counterpart in the reference.  Calls no
- * hipMalloc / hipFree.  Limit: tables of at most HYAS_NOALLOC_MAX_KEYS keys (hyas_table_dims: (headings + 1) * w * h *
+ * hipMalloc / hipFree.  Like every call here it launches on the context's own stream and waits for it, so it is not
+ * for use inside a HIP graph capture.  Limit: tables of at most HYAS_NOALLOC_MAX_KEYS keys (hyas_table_dims: (headings + 1) * w * h *
  * position_resolution^2 + w * position_resolution), HYAS_ERANGE beyond.  All contexts on one GPU share that GPU's
  * array: calls that overlap on one GPU race; consecutive calls are safe (every call resets the ranks it uses). */
 #define HYAS_NOALLOC_MAX_KEYS (1u << 20)
@@ -266,8 +277,14 @@ int hyas_get_expanded(const hyas_ctx *ctx, size_t i, int32_t *idx, size_t cap);
  * hyas_plan_batch / *_batch call, measured with HIP events on the streams the
  * kernels were launched on, summed over launches; *launches receives their
  * number.  which: 0 search round (hyas_plan_batch) or shot (hyas_shot_batch),
- * 1 successors (hyas_expand_batch), 2 collision batch, 3 table build, 4 unused. */
+ * 1 successors (hyas_expand_batch), 2 collision batch, 3 table build, 4 unused.
+ * The search rounds of hyas_plan_batch carry timing events only after
+ * hyas_set_round_timing(ctx, k) with k > 0 (every 2k-th launch of a query group
+ * is then timed and the sum scaled up; k = 0, the default, records none: two
+ * event records lengthen a launch call by 2-3 us); the launch count is kept
+ * either way.  No counterpart in the reference. */
 double hyas_last_kernel_ms(const hyas_ctx *ctx, int which, int64_t *launches);
+int hyas_set_round_timing(hyas_ctx *ctx, int every);
 void hyas_reset_kernel_timers(hyas_ctx *ctx);
 
 /* Work counters of the expansion-step kernel, for roofline accounting (no

@@ -20,8 +20,9 @@
  * fixture ("parity unpinned"): collision verdicts, successor sets, g/h,
  * expansion order (Boost binomial-heap tie order is replaced by
  * "lowest f, then earliest push"), costmap_2d::worldToMap (restated from its
- * documented semantics), OMPL's Reeds-Shepp/Dubins distance (the in-tree
- * ReedsShepp.cpp stands in for it).
+ * documented semantics), OMPL's Reeds-Shepp distance (the in-tree
+ * ReedsShepp.cpp stands in for it) and OMPL's Dubins distance (restated from
+ * OMPL's published source, double arithmetic as there).
  */
 #include <algorithm>
 #include <array>
@@ -934,6 +935,158 @@ static void rsSample(const double q0[3], const double q1[3], double rho, double 
         points.push_back(q);
     }
 }
+
+// ------------------------------------------------------------ OMPL's Dubins distance
+// src/lookup_table.cpp:152, :174 call ompl::base::DubinsStateSpace::distance, which is not in the reference tree (OMPL is
+// a system dependency, version unpinned: CMakeLists.txt:40).  Restated from OMPL's published source,
+// src/ompl/base/spaces/src/DubinsStateSpace.cpp (releases 1.4 - 1.6): one function per word as there, double arithmetic,
+// OMPL's tolerances.  PARITY UNPINNED: no file of the reference holds an output of this function.
+namespace ompl_dubins
+{
+const double twopi = 2. * kPi;
+const double DUBINS_EPS = 1e-6;
+const double DUBINS_ZERO = -1e-7;
+struct DubinsPath
+{
+    double length_[3];
+    DubinsPath(double t = 0., double p = std::numeric_limits<double>::max(), double q = 0.) { length_[0] = t, length_[1] = p, length_[2] = q; }
+    double length() const { return length_[0] + length_[1] + length_[2]; }
+};
+static inline double mod2pi(double x)
+{
+    if (x < 0 && x > DUBINS_ZERO)
+        return 0;
+    double xm = x - twopi * std::floor(x / twopi);
+    if (twopi - xm < .5 * DUBINS_EPS)
+        xm = 0.;
+    return xm;
+}
+static DubinsPath dubinsLSL(double d, double alpha, double beta)
+{
+    double ca = m_cos(alpha), sa = m_sin(alpha), cb = m_cos(beta), sb = m_sin(beta);
+    double tmp = 2. + d * d - 2. * (ca * cb + sa * sb - d * (sa - sb));
+    if (tmp >= DUBINS_ZERO)
+    {
+        double theta = m_atan2(cb - ca, d + sa - sb);
+        double t = mod2pi(-alpha + theta);
+        double p = std::sqrt(std::max(tmp, 0.));
+        double q = mod2pi(beta - theta);
+        return DubinsPath(t, p, q);
+    }
+    return DubinsPath();
+}
+static DubinsPath dubinsRSR(double d, double alpha, double beta)
+{
+    double ca = m_cos(alpha), sa = m_sin(alpha), cb = m_cos(beta), sb = m_sin(beta);
+    double tmp = 2. + d * d - 2. * (ca * cb + sa * sb - d * (sb - sa));
+    if (tmp >= DUBINS_ZERO)
+    {
+        double theta = m_atan2(ca - cb, d - sa + sb);
+        double t = mod2pi(alpha - theta);
+        double p = std::sqrt(std::max(tmp, 0.));
+        double q = mod2pi(-beta + theta);
+        return DubinsPath(t, p, q);
+    }
+    return DubinsPath();
+}
+static DubinsPath dubinsRSL(double d, double alpha, double beta)
+{
+    double ca = m_cos(alpha), sa = m_sin(alpha), cb = m_cos(beta), sb = m_sin(beta);
+    double tmp = d * d - 2. + 2. * (ca * cb + sa * sb - d * (sa + sb));
+    if (tmp >= DUBINS_ZERO)
+    {
+        double p = std::sqrt(std::max(tmp, 0.));
+        double theta = m_atan2(ca + cb, d - sa - sb) - m_atan2(2., p);
+        double t = mod2pi(alpha - theta);
+        double q = mod2pi(beta - theta);
+        return DubinsPath(t, p, q);
+    }
+    return DubinsPath();
+}
+static DubinsPath dubinsLSR(double d, double alpha, double beta)
+{
+    double ca = m_cos(alpha), sa = m_sin(alpha), cb = m_cos(beta), sb = m_sin(beta);
+    double tmp = -2. + d * d + 2. * (ca * cb + sa * sb + d * (sa + sb));
+    if (tmp >= DUBINS_ZERO)
+    {
+        double p = std::sqrt(std::max(tmp, 0.));
+        double theta = m_atan2(-ca - cb, d + sa + sb) - m_atan2(-2., p);
+        double t = mod2pi(-alpha + theta);
+        double q = mod2pi(-beta + theta);
+        return DubinsPath(t, p, q);
+    }
+    return DubinsPath();
+}
+static DubinsPath dubinsRLR(double d, double alpha, double beta)
+{
+    double ca = m_cos(alpha), sa = m_sin(alpha), cb = m_cos(beta), sb = m_sin(beta);
+    double tmp = .125 * (6. - d * d + 2. * (ca * cb + sa * sb + d * (sa - sb)));
+    if (std::fabs(tmp) < 1.)
+    {
+        double p = twopi - m_acos(tmp);
+        double theta = m_atan2(ca - cb, d - sa + sb);
+        double t = mod2pi(alpha - theta + .5 * p);
+        double q = mod2pi(alpha - beta - t + p);
+        return DubinsPath(t, p, q);
+    }
+    return DubinsPath();
+}
+static DubinsPath dubinsLRL(double d, double alpha, double beta)
+{
+    double ca = m_cos(alpha), sa = m_sin(alpha), cb = m_cos(beta), sb = m_sin(beta);
+    double tmp = .125 * (6. - d * d + 2. * (ca * cb + sa * sb - d * (sa - sb)));
+    if (std::fabs(tmp) < 1.)
+    {
+        double p = twopi - m_acos(tmp);
+        double theta = m_atan2(-ca + cb, d + sa - sb);
+        double t = mod2pi(-alpha + theta + .5 * p);
+        double q = mod2pi(beta - alpha - t + p);
+        return DubinsPath(t, p, q);
+    }
+    return DubinsPath();
+}
+static DubinsPath dubins(double d, double alpha, double beta)
+{
+    if (d < DUBINS_EPS && std::fabs(alpha - beta) < DUBINS_EPS)
+        return DubinsPath(0, d, 0);
+    DubinsPath path(dubinsLSL(d, alpha, beta)), tmp(dubinsRSR(d, alpha, beta));
+    double len, minLength = path.length();
+    if ((len = tmp.length()) < minLength)
+    {
+        minLength = len;
+        path = tmp;
+    }
+    tmp = dubinsRSL(d, alpha, beta);
+    if ((len = tmp.length()) < minLength)
+    {
+        minLength = len;
+        path = tmp;
+    }
+    tmp = dubinsLSR(d, alpha, beta);
+    if ((len = tmp.length()) < minLength)
+    {
+        minLength = len;
+        path = tmp;
+    }
+    tmp = dubinsRLR(d, alpha, beta);
+    if ((len = tmp.length()) < minLength)
+    {
+        minLength = len;
+        path = tmp;
+    }
+    tmp = dubinsLRL(d, alpha, beta);
+    if ((len = tmp.length()) < minLength)
+        path = tmp;
+    return path;
+}
+// DubinsStateSpace::distance for the default (not symmetric) space of turning radius rho
+static double distance(double x1, double y1, double th1, double x2, double y2, double th2, double rho)
+{
+    double dx = x2 - x1, dy = y2 - y1, d = std::sqrt(dx * dx + dy * dy) / rho, th = m_atan2(dy, dx);
+    double alpha = mod2pi(th1 - th), beta = mod2pi(th2 - th);
+    return rho * dubins(d, alpha, beta).length();
+}
+} // namespace ompl_dubins
 
 // ----------------------------------------------------------------------- Dubins
 // src/dubins.cpp:81-314, float arithmetic as the reference's <math.h> float
@@ -2039,7 +2192,7 @@ struct Ctx
         // OMPL's {ReedsShepp,Dubins}StateSpace::distance (double state
         // (x, y, yaw) from float loop variables), src/lookup_table.cpp:172-174,
         // :212-214.  Reeds-Shepp: the in-tree ReedsShepp.cpp algorithm.
-        // Dubins: OMPL is absent; the in-tree Walker solver (float) stands in.
+        // Dubins: OMPL's algorithm restated (ompl_dubins above), double as there.
         if (curve == HYAS_CURVE_RS)
         {
             double q0[3] = {0, 0, 0}, q1[3] = {x, y, theta};
@@ -2047,11 +2200,7 @@ struct Ctx
         }
         if (curve == HYAS_CURVE_BEZIER) // CalculateCubicBezierLookupV1, src/lookup_table.cpp:226-277
             return bez::tableCost(x, y, theta);
-        float q0[3] = {0, 0, 0}, q1[3] = {x, y, theta};
-        db::Path p;
-        if (db::init(q0, q1, P.cd_min_turning_radius, &p) != 0)
-            return 1000000;
-        return db::length(&p);
+        return ompl_dubins::distance(0., 0., 0., (double)x, (double)y, (double)theta, (double)P.cd_min_turning_radius);
     }
     // The float accumulators of src/lookup_table.cpp:158-183 / :197-222.
     void tableAxes(std::vector<float> &xs, std::vector<float> &ys, std::vector<float> &ts) const

@@ -78,7 +78,7 @@ EXPORTS = [
     "hyas_collision_batch_dev", "hyas_footprint_table", "hyas_expand_batch", "hyas_num_successors",
     "hyas_shot_batch", "hyas_twod_size", "hyas_flood", "hyas_table_dims", "hyas_table_build_dev",
     "hyas_table_install_dev", "hyas_table_lookup", "hyas_plan_batch", "hyas_get_path", "hyas_get_expanded",
-    "hyas_last_kernel_ms", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats", "hyas_nodes_in_device_memory",
+    "hyas_last_kernel_ms", "hyas_set_round_timing", "hyas_reset_kernel_timers", "hyas_set_stats", "hyas_get_stats", "hyas_nodes_in_device_memory",
     "hyas_table_install_noalloc_dev", "hyas_shortcut_batch", "hyas_expand_batch_from", "hyas_adaptive_cell",
 ]
 
@@ -150,6 +150,9 @@ def load_library():
     L.hyas_set_stats.argtypes = [C.c_void_p, C.c_int]
     L.hyas_get_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.hyas_nodes_in_device_memory.argtypes = [C.c_void_p]
+    L.hyas_set_round_timing.argtypes = [C.c_void_p, C.c_int]
+    L.hyas_expand_batch_from.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.hyas_adaptive_cell.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -399,6 +402,10 @@ class Hyas:
 
     def nodes_in_device_memory(self):
         return self.L.hyas_nodes_in_device_memory(self.h) == 1
+
+    def set_round_timing(self, every):
+        """0 (default): the search rounds carry no timing events; k > 0: every 2k-th launch of a query group is timed."""
+        self._check(self.L.hyas_set_round_timing(self.h, int(every)), "hyas_set_round_timing")
 
     def set_stats(self, mode):
         """0 off, 1 work counters, 2 phase clocks."""

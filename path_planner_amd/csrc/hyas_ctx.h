@@ -99,6 +99,7 @@ struct hyas_ctx
     double k_ms[5] = {0, 0, 0, 0, 0};
     int64_t k_launches[5] = {0, 0, 0, 0, 0};
     unsigned long long *d_stats = nullptr; // 8 work counters of the step kernel
+    int round_timing = 0; // hyas_set_round_timing
     bool stats_on = false;
     int stats_mode = 0; // 1 work counters, 2 phase clocks
 

@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <limits>
+#include <mutex>
 
 using namespace hyas;
 
@@ -668,6 +669,8 @@ hyas_ctx *hyas_create(const hyas_params *params, int device)
     }
     if (hipSetDevice(device) != hipSuccess)
         return nullptr;
+    static std::mutex scratch_mu; // contexts may be created from several threads
+    std::lock_guard<std::mutex> scratch_lock(scratch_mu);
     if (device < HYAS_MAX_DEVICES && !scratch_ptr[device])
     {
         // this device's copy of the static scratch array (the device is current)
@@ -781,6 +784,7 @@ static void fill_motion_set(hyas_ctx *c)
     m.ad_fixed_number = c->P.fixed_number_of_steering_angle_in_free_angle_range != 0;
     m.pen_turn = c->P.penalty_turning, m.pen_rev = c->P.penalty_reverse, m.pen_cod = c->P.penalty_change_of_direction;
     m.shot_rho = c->P.min_turning_radius;
+    m.max_steer = c->P.max_steering_angle;
     m.curve_type = c->P.curve_type;
 }
 
@@ -1538,6 +1542,14 @@ int hyas_set_stats(hyas_ctx *c, int enable)
     c->stats_mode = enable;
     HYAS_HIP(c, hipSetDevice(c->device));
     HYAS_HIP(c, hipMemset(c->d_stats, 0, 24 * sizeof(unsigned long long)));
+    return HYAS_OK;
+}
+
+int hyas_set_round_timing(hyas_ctx *c, int every)
+{
+    if (!c || every < 0)
+        return HYAS_EINVAL;
+    c->round_timing = every;
     return HYAS_OK;
 }
 

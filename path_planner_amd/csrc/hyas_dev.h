@@ -130,6 +130,7 @@ struct DevMap
     int32_t succ_reverse[HYAS_MAX_SUCC];
     float pen_turn, pen_rev, pen_cod;
     float shot_rho; // params.min_turning_radius
+    float max_steer; // params.max_steering_angle: ShortCut keeps a node whose steering towards the anchor is not below it
     int32_t curve_type;
     uint32_t twod_size; // floats per 2D cost map: w*h + w + 1
     // Dubins shot: sample positions x_k of `x += 0.2 * res` in float (src/hybrid_a_star.cpp:396-424)
@@ -771,6 +772,14 @@ HD float heuristic(const DevMap &m, float x, float y, float t, float gx, float g
         }
     }
     return fmaxf_(curve, two_d);
+}
+
+// Utility::FindSteeringAngle(closest, direction), src/utility.cpp:2111-2117, over GetAngle (:1288-1296): the signed angle
+// from closest's heading to the direction in which `direction` lies
+HD float find_steering_angle(float cx, float cy, float ct, float dx, float dy)
+{
+    const float angle_between = rad_norm(rad_0_2pi(hy_atan2f(dy - cy, dx - cx)));
+    return -rad_norm(rad_norm(ct) - angle_between);
 }
 
 // ------------------------------------------------------------- successors

@@ -191,5 +191,106 @@ DB_HD int sample(const Path &p, float t, float q[3])
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The Dubins distance of the heuristic table (src/lookup_table.cpp:147-185): the reference calls
+// ompl::base::DubinsStateSpace::distance, double arithmetic, which is not part of the reference tree.  This restates
+// OMPL's published algorithm (ompl/base/spaces/src/DubinsStateSpace.cpp, releases 1.4 - 1.6: the six words of Shkel and
+// Lumelsky's classification with OMPL's own tolerances DUBINS_EPS = 1e-6 and DUBINS_ZERO = -1e-7), words tried in
+// OMPL's order LSL, RSR, RSL, LSR, RLR, LRL with a strictly shorter word replacing the current one.  A word that does
+// not connect has OMPL's default length, the largest double.  No reference fixture holds an output of it.
+namespace ompl
+{
+#define DB_OMPL_EPS 1e-6
+#define DB_OMPL_ZERO (-1e-7)
+#define DB_OMPL_MAX 1.7976931348623157e308
+DB_HD double mod2pi(double x)
+{
+    const double twopi = 2. * HY_PI;
+    if (x < 0 && x > DB_OMPL_ZERO)
+        return 0;
+    double xm = x - twopi * hy_floor(x / twopi);
+    if (twopi - xm < .5 * DB_OMPL_EPS)
+        xm = 0.;
+    return xm;
+}
+// length t + p + q of word w (0 LSL, 1 RSR, 2 RSL, 3 LSR, 4 RLR, 5 LRL) between headings alpha and beta at distance d
+DB_HD double word_length(int w, double d, double alpha, double beta, double sa, double ca, double sb, double cb)
+{
+    const double twopi = 2. * HY_PI;
+    double t, p, q;
+    if (w == 0)
+    {
+        const double tmp = 2. + d * d - 2. * (ca * cb + sa * sb - d * (sa - sb));
+        if (!(tmp >= DB_OMPL_ZERO))
+            return DB_OMPL_MAX;
+        const double theta = hy_atan2(cb - ca, d + sa - sb);
+        t = mod2pi(-alpha + theta), p = hy_sqrt(tmp > 0. ? tmp : 0.), q = mod2pi(beta - theta);
+    }
+    else if (w == 1)
+    {
+        const double tmp = 2. + d * d - 2. * (ca * cb + sa * sb - d * (sb - sa));
+        if (!(tmp >= DB_OMPL_ZERO))
+            return DB_OMPL_MAX;
+        const double theta = hy_atan2(ca - cb, d - sa + sb);
+        t = mod2pi(alpha - theta), p = hy_sqrt(tmp > 0. ? tmp : 0.), q = mod2pi(-beta + theta);
+    }
+    else if (w == 2)
+    {
+        const double tmp = d * d - 2. + 2. * (ca * cb + sa * sb - d * (sa + sb));
+        if (!(tmp >= DB_OMPL_ZERO))
+            return DB_OMPL_MAX;
+        p = hy_sqrt(tmp > 0. ? tmp : 0.);
+        const double theta = hy_atan2(ca + cb, d - sa - sb) - hy_atan2(2., p);
+        t = mod2pi(alpha - theta), q = mod2pi(beta - theta);
+    }
+    else if (w == 3)
+    {
+        const double tmp = -2. + d * d + 2. * (ca * cb + sa * sb + d * (sa + sb));
+        if (!(tmp >= DB_OMPL_ZERO))
+            return DB_OMPL_MAX;
+        p = hy_sqrt(tmp > 0. ? tmp : 0.);
+        const double theta = hy_atan2(-ca - cb, d + sa + sb) - hy_atan2(-2., p);
+        t = mod2pi(-alpha + theta), q = mod2pi(-beta + theta);
+    }
+    else if (w == 4)
+    {
+        const double tmp = .125 * (6. - d * d + 2. * (ca * cb + sa * sb + d * (sa - sb)));
+        if (!(hy_fabs(tmp) < 1.))
+            return DB_OMPL_MAX;
+        p = twopi - hy_acos(tmp);
+        const double theta = hy_atan2(ca - cb, d - sa + sb);
+        t = mod2pi(alpha - theta + .5 * p), q = mod2pi(alpha - beta - t + p);
+    }
+    else
+    {
+        const double tmp = .125 * (6. - d * d + 2. * (ca * cb + sa * sb - d * (sa - sb)));
+        if (!(hy_fabs(tmp) < 1.))
+            return DB_OMPL_MAX;
+        p = twopi - hy_acos(tmp);
+        const double theta = hy_atan2(-ca + cb, d + sa - sb);
+        t = mod2pi(-alpha + theta + .5 * p), q = mod2pi(beta - alpha - t + p);
+    }
+    return t + p + q;
+}
+// DubinsStateSpace::distance((x1, y1, th1), (x2, y2, th2)) for turning radius rho (not symmetric: the default)
+DB_HD double distance(double x1, double y1, double th1, double x2, double y2, double th2, double rho)
+{
+    const double dx = x2 - x1, dy = y2 - y1, d = hy_sqrt(dx * dx + dy * dy) / rho, th = hy_atan2(dy, dx);
+    const double alpha = mod2pi(th1 - th), beta = mod2pi(th2 - th);
+    if (d < DB_OMPL_EPS && hy_fabs(alpha - beta) < DB_OMPL_EPS)
+        return rho * (0. + d + 0.);
+    double sa, ca, sb, cb;
+    hy_sincos(alpha, &sa, &ca), hy_sincos(beta, &sb, &cb);
+    double best = word_length(0, d, alpha, beta, sa, ca, sb, cb);
+    for (int w = 1; w < 6; ++w)
+    {
+        const double len = word_length(w, d, alpha, beta, sa, ca, sb, cb);
+        if (len < best)
+            best = len;
+    }
+    return rho * best;
+}
+} // namespace ompl
+
 } // namespace db
 } // namespace hyas

@@ -42,14 +42,15 @@ __global__ void __launch_bounds__(256) k_collision_polygon(DevMap m, const float
 }
 
 // Footprint-list mode: 4 poses per thread so the verdict store is one dword.
+// (aligned == false: xyt is not 16-byte or out not 4-byte aligned; every access is then a scalar one)
 __global__ void __launch_bounds__(256) k_collision_footprint(DevMap m, const float *__restrict__ xyt, size_t n,
-                                                             uint8_t *__restrict__ out)
+                                                             uint8_t *__restrict__ out, bool aligned)
 {
     const size_t groups = (n + 3) / 4;
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x)
     {
         const size_t i0 = g * 4;
-        if (i0 + 4 <= n)
+        if (aligned && i0 + 4 <= n)
         {
             // 48 contiguous bytes per thread: three 16-byte loads
             const float4 *p = reinterpret_cast<const float4 *>(xyt + 3 * i0);
@@ -610,8 +611,8 @@ __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, 
     }
 }
 
-// The same for curve_type 0 (src/lookup_table.cpp:147-180).  OMPL's DubinsStateSpace is not part of the
-// reference tree; the in-tree float solver (src/dubins.cpp) stands in, 1e6 where no word connects.
+// The same for curve_type 0 (src/lookup_table.cpp:147-180): OMPL's DubinsStateSpace::distance in double
+// (db::ompl::distance, hyas_dubins.h), stored as float.
 __global__ void __launch_bounds__(256) k_table_dubins(const float *__restrict__ xs, uint32_t nx,
                                                       const float *__restrict__ ys, uint32_t ny,
                                                       const float *__restrict__ ts, uint32_t k0, uint32_t k1, float rho,
@@ -623,9 +624,7 @@ __global__ void __launch_bounds__(256) k_table_dubins(const float *__restrict__ 
         uint32_t i = (uint32_t)(e % nx);
         uint32_t j = (uint32_t)((e / nx) % ny);
         uint32_t k = k0 + (uint32_t)(e / ((size_t)nx * ny));
-        const float a[3] = {0, 0, 0}, b[3] = {xs[i], ys[j], ts[k]};
-        db::Path p;
-        out[e] = (db::init(a, b, rho, p) != 0) ? 1000000.f : db::length(p);
+        out[e] = (float)db::ompl::distance(0., 0., 0., (double)xs[i], (double)ys[j], (double)ts[k], (double)rho);
     }
 }
 
@@ -1865,8 +1864,10 @@ __global__ void __launch_bounds__(64) k_bezier_points(const float *__restrict__ 
 // node the reference walks towards its first for as long as CollisionDetection::IsTraversable(current, node)
 // (src/collisiondetection.cpp:129-145: both poses free and the segment between them) holds, keeps the last node that
 // passed, and starts again two nodes further down.  The walk of one anchor is a search for the first failing node:
-// the workgroup tests 256 candidates at a time and stops at the first chunk that holds a failure.  The steering-angle
-// test of the reference compares radians with max_steering_angle = 30 and passes for every finite angle.
+// the workgroup tests 256 candidates at a time and stops at the first chunk that holds a failure.  A node fails either
+// because it is not traversable from the anchor (:1135-1150: the node kept is the last one that passed) or because the
+// steering angle from it towards the anchor is not below max_steering_angle (:1097-1125: the node itself is kept).  (The
+// reference compares radians with a limit whose default is 30: every finite angle passes unless the limit is lowered.)
 // A path of fewer than two nodes is returned unchanged (the reference reads input[size - 2] first: undefined there).
 // paths: all poses {x, y, t}, path q = poses [offs[q], offs[q + 1]); out_idx + offs[q] + q: up to len + 1 input indices in
 // the order the reference pushes them (last node first; the caller reverses), out_n[q] their number.
@@ -1902,9 +1903,9 @@ __global__ void __launch_bounds__(256) k_shortcut(DevMap m, const float *__restr
         }
         ++count;
         __syncthreads();
-        int fail = -1; // highest node below index1 that is not traversable from it
+        int fail = -1; // highest node below index1 that fails, as node << 1 | (1: on its steering angle)
         if (!s_cur_free)
-            fail = index1 - 1;
+            fail = (index1 - 1) << 1;
         else
             for (int j0 = index1 - 1; j0 >= 0; j0 -= 256)
             {
@@ -1914,7 +1915,9 @@ __global__ void __launch_bounds__(256) k_shortcut(DevMap m, const float *__restr
                     const float px = P[3 * j], py = P[3 * j + 1], pt = P[3 * j + 2];
                     const bool ok = on_grid(m, px, py) && segment_free(m, gq, cx, cy, px, py) && pose_free(m, gq, px, py, pt);
                     if (!ok)
-                        atomicMax(&s_fail, j);
+                        atomicMax(&s_fail, j << 1);
+                    else if (!(hy_fabsf(find_steering_angle(px, py, pt, cx, cy)) < m.max_steer))
+                        atomicMax(&s_fail, j << 1 | 1);
                 }
                 __syncthreads();
                 fail = s_fail;
@@ -1929,7 +1932,11 @@ __global__ void __launch_bounds__(256) k_shortcut(DevMap m, const float *__restr
             ++count;
             break;
         }
-        if (fail + 1 <= index1 - 1)
+        const bool on_steering = (fail & 1) != 0;
+        fail >>= 1;
+        if (on_steering)
+            prev = fail; // the node itself (:1094, :1113)
+        else if (fail + 1 <= index1 - 1)
             prev = fail + 1; // the last node that passed; none: the one kept from before (:1138)
         if (tid == 0)
             out[count] = (uint32_t)prev;
@@ -2148,7 +2155,11 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
     if (n == 0)
         return;
     static const bool force_packed_lists = std::getenv("HYAS_FP_PACKED_LISTS") != nullptr; // the per-cell kernel, for comparison
-    if (mode == HYAS_MODE_FOOTPRINT && m.fp_m8 && m.occ_pad && !force_packed_lists)
+    // the batched footprint kernels load poses 16 bytes and store verdicts 4 bytes at a time
+    const bool aligned = ((uintptr_t)xyt & 15u) == 0 && ((uintptr_t)out & 3u) == 0;
+    if (mode == HYAS_MODE_FOOTPRINT && !aligned)
+        hipLaunchKernelGGL(k_collision_footprint, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, m, xyt, n, out, false);
+    else if (mode == HYAS_MODE_FOOTPRINT && m.fp_m8 && m.occ_pad && !force_packed_lists)
     {
         // one workgroup of sixteen waves per compute unit: bitmaps (8 bytes per list) and the waves' pose strips in LDS
         const int threads = 1024;
@@ -2197,7 +2208,7 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
         }
     }
     else if (mode == HYAS_MODE_FOOTPRINT)
-        hipLaunchKernelGGL(k_collision_footprint, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, m, xyt, n, out);
+        hipLaunchKernelGGL(k_collision_footprint, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, m, xyt, n, out, true);
     else
         hipLaunchKernelGGL(k_collision_polygon, dim3(grid_for(n)), dim3(256), 0, s, m, xyt, pred_xy, n, out);
 }

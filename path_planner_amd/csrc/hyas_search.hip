@@ -863,9 +863,10 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     if (m.ad_mode != 0)
         tree_cfg = 0;
     const int ahead_nodes = tree_cfg ? tree_cfg : ahead_cfg * ahead_width; // nodes of a query that do not exist yet, at most
-    // rounds between the pairs of timing events behind hyas_kernel_ms (the figure is scaled up from the timed launches):
-    // every round for large calls, every 16th where a round is short enough for two event records to show
-    const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : (n <= 64 ? 16 : 1);
+    // Timing events around the launches of a round, behind hyas_last_kernel_ms(ctx, 0): off unless hyas_set_round_timing
+    // (or HYAS_EVENT_EVERY) asks for them; every 2 k-th launch of a group then carries a pair, and the figure is scaled
+    // up from the timed launches.  (Two event records lengthen a launch call by 2-3 us: 3-4 % of a maze batch.)
+    const int64_t ev_every = std::getenv("HYAS_EVENT_EVERY") ? std::max(0, std::atoi(std::getenv("HYAS_EVENT_EVERY"))) : std::max(0, c->round_timing);
     std::vector<float> shot_buf;
     // a failed HIP call may leave kernels of other groups in flight that write into the staging block: wait for them
     auto drain = [&](int rc) {
@@ -1780,7 +1781,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 return drain(c->fail(G[gi].rc, "a HIP call failed in a search round"));
             // kernel time of all launches, from the ones that carried timing events
             if (G[gi].timed_launches > 0)
-                c->k_ms[0] += G[gi].k_ms * (double)G[gi].launches / (double)G[gi].timed_launches, c->k_launches[0] += G[gi].launches;
+                c->k_ms[0] += G[gi].k_ms * (double)G[gi].launches / (double)G[gi].timed_launches;
+            c->k_launches[0] += G[gi].launches;
             t_host += (double)G[gi].host_ns.load() * 1e-9, t_launch += G[gi].t_launch;
         }
 

@@ -17,23 +17,56 @@ def load_map(name):
 def launch_ranks(script, argv, n, timeout=None):
     """Starts `n` processes of `script argv...`, one per GPU, with the torch.distributed environment
     (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR, MASTER_PORT) set, before this process has touched a
-    GPU.  Returns (exit codes, rank 0's stdout).  Ranks other than 0 inherit stdout / stderr."""
+    GPU.  Returns (exit codes, rank 0's stdout).  Ranks other than 0 inherit stdout / stderr.  All ranks are watched
+    together: as soon as one exits with a failure, or `timeout` seconds have passed, the others are terminated (they
+    would otherwise sit in a rendezvous or a collective until its own timeout) and reaped; a rank that had to be stopped
+    reports a negative code (its signal) or, after the time limit, 124."""
     import os
     import socket
     import subprocess
     import sys
+    import threading
+    import time
 
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     procs = []
-    for r in range(n):
-        procs.append(subprocess.Popen([sys.executable, str(script)] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
-    out0, _ = procs[0].communicate(timeout=timeout)
-    codes = [procs[0].returncode] + [p.wait(timeout=timeout) for p in procs[1:]]
-    return codes, out0
+    out0 = []
+    reader = None
+    timed_out = False
+    try:
+        for r in range(n):
+            procs.append(subprocess.Popen([sys.executable, str(script)] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                          stdout=subprocess.PIPE if r == 0 else None, text=True))
+        # rank 0's pipe is drained on a thread of its own, so that a full pipe never blocks the rank
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = None if timeout is None else time.monotonic() + timeout
+        while True:
+            codes_now = [p.poll() for p in procs]  # every rank is asked, not only up to the first one still running
+            if all(c is not None for c in codes_now) or any(c not in (None, 0) for c in codes_now):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                timed_out = True
+                break
+            time.sleep(0.05)
+    finally:
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_kill = time.monotonic() + 5
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        if reader is not None:
+            reader.join(timeout=5)
+    codes = [124 if (timed_out and p.returncode is not None and p.returncode < 0) else p.returncode for p in procs]
+    return codes, (out0[0] if out0 else "")
 
 
 def query_shard(n_total, rank, world):
@@ -109,6 +142,16 @@ def aggregate(dist, local_seconds, local_counts):
     c = torch.tensor([float(v) for v in local_counts], dtype=torch.float64, device=dev)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), [float(v) for v in c.tolist()]
+
+
+def result_digest(res):
+    """What a planning batch answered, in two numbers that a benchmark line and a test can both state: the CRC-32 of the
+    result records (status, counters, path length and costs of every query, in query order) and the nodes expanded."""
+    import zlib
+
+    res = np.ascontiguousarray(res)
+    return {"crc32_of_result_records": int(zlib.crc32(res.tobytes())), "nodes_expanded": int(res["nodes_expanded"].sum()),
+            "queries": int(len(res))}
 
 
 def make_queries(collision_fn, n, seed, width, height):

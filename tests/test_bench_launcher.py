@@ -12,9 +12,10 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(*argv, timeout=300):
+def _run(*argv, timeout=300, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
+    env.update(extra_env)
     return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
 
 
@@ -45,3 +46,16 @@ def test_bench_without_gpu_fails_on_every_rank():
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr and "ranks failed" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no line without a measurement
+
+
+def test_one_failing_rank_ends_the_others():
+    """Rank 1 exits before the rendezvous; rank 0 would wait in it for minutes.  The launcher must notice, stop rank 0
+    and report both: well inside the rendezvous timeout, and without a line on stdout."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run("--gpus", "2", "--dry-run", timeout=120, HYAS_DRY_RUN_FAIL_RANK="1")
+    assert time.monotonic() - t0 < 60
+    assert r.returncode != 0 and "ranks failed" in r.stderr
+    assert "(1, 3)" in r.stderr  # rank 1's own exit code; rank 0 was terminated (negative code)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -103,15 +103,15 @@ def test_rs_table_180x60_at_position_resolution_10(oracle_built):
 
 
 def test_large_map_full_depth_searches(oracle_built):
-    """48 queries of the 65 536-query batch (map_large, seed 3, every 1365th) at max_iterations = 10 000 against the
+    """256 queries of the 65 536-query batch (map_large, seed 3, every 256th) at max_iterations = 10 000 against the
     oracle: result records, expansion order, paths."""
     o, h, mp = _pair("map_large")
     H, W = mp.shape
     S, G = make_queries(h.collision, 65536, 3, W, H)
-    pick = np.arange(0, 65536, 1365)[:48]
+    pick = np.arange(0, 65536, 256)[:256]
     S, G = S[pick], G[pick]
     res = h.plan_batch(S, G)
-    assert (res["nodes_expanded"] > 2000).sum() >= 4
+    assert (res["nodes_expanded"] > 2000).sum() >= 16
     assert _compare_threaded(o, h, S, G, res) == []
 
 
@@ -166,3 +166,70 @@ def test_shortcut_paths_against_oracle(oracle_built):
         want = o.shortcut(p)
         assert np.array_equal(want, g), (len(p), want[:10], g[:10])
     assert sum(len(g) for g in got) < sum(len(p) for p in paths)
+    # with a steering limit that bites (radians; the reference's default of 30 never does): nodes are also kept because
+    # the steering from them towards the anchor is at or beyond the limit (src/hybrid_a_star.cpp:1097-1125)
+    kept = {}
+    for limit in (0.05, 0.3, 1.0, 3.0):
+        o2, h2, _ = _pair("map_maze", position_resolution=2, max_iterations=10, analytical_expansion=0, max_steering_angle=limit)
+        got2 = h2.shortcut(paths)
+        for p, g in zip(paths, got2):
+            want = o2.shortcut(p)
+            assert np.array_equal(want, g), (limit, len(p), want[:10], g[:10])
+        kept[limit] = sum(len(g) for g in got2)
+    assert kept[0.05] > kept[3.0] >= sum(len(g) for g in got)  # a tighter limit keeps more nodes
+
+
+def test_sharded_table_build_matches_the_single_build(oracle_built):
+    """The benchmark's table path (sharding.build_table_sharded: slices on this GPU, gather, install) against the table
+    hyas_set_costmap builds by itself: every lookup bit for bit, Reeds-Shepp and Dubins."""
+    import torch
+
+    from path_planner_amd import sharding
+
+    mp = orc.load_map("map_parking")
+    rng = np.random.default_rng(9)
+    q = np.stack([rng.uniform(0, 60, 200000), rng.uniform(0, 30, 200000), rng.uniform(-7, 7, 200000)], 1).astype(np.float32)
+    for curve in (1, 0):
+        p = hot_path_params(position_resolution=3, cd_min_turning_radius=0.35, curve_type=curve)
+        a = Hyas(p)
+        a.set_costmap(mp, build_table=True)
+        b = Hyas(p)
+        b.set_costmap(mp, build_table=False)
+        sharding.build_table_sharded(b, curve, None, device=torch.device("cuda", 0))
+        assert np.array_equal(a.table_lookup(q).view(np.uint32), b.table_lookup(q).view(np.uint32)), curve
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_table_from_several_processes(world, tmp_path, oracle_built):
+    """`world` processes (all on GPU 0, joined over gloo) each build their heading slices with the HIP kernel; after the
+    all-gather every rank must answer lookups exactly like a context that built the whole table alone."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    rng = np.random.default_rng(10)
+    q = np.stack([rng.uniform(0, 60, 100000), rng.uniform(0, 30, 100000), rng.uniform(-7, 7, 100000)], 1).astype(np.float32)
+    np.save(tmp_path / "lookups.npy", q)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(root / "tests" / "dist_gpu_worker.py"), str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(world)]
+    try:
+        for pr in procs:
+            assert pr.wait(timeout=240) == 0
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    h = Hyas(hot_path_params(position_resolution=2, cd_min_turning_radius=0.35))
+    h.set_costmap(orc.load_map("map_parking"), build_table=True)
+    want = h.table_lookup(q)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}.npy").view(np.uint32), want.view(np.uint32)), r
+        assert json.loads((tmp_path / f"rank{r}.json").read_text())["dims"][2] == 73

@@ -2,7 +2,9 @@
 oracle on every element: determinism, independence of batch composition, paths that start and end where asked
 and are collision-free, sharded table builds that tile the single build, verdict counts against the oracle where
 the oracle is fast enough to run in full."""
+import json
 import math
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -10,9 +12,37 @@ import pytest
 import orc
 from path_planner_amd import Hyas, Params, default_params, hot_path_params
 from path_planner_amd import _lib as hl
-from path_planner_amd.sharding import heading_slices, make_queries
+from path_planner_amd.sharding import heading_slices, make_queries, result_digest
 
 pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def _compare_threaded(map_name, params_kw, S, G, res, got, which):
+    """Queries `which` against the CPU oracle, one oracle context per thread: result record, ordered expanded cells and
+    path poses must be bit-identical.  Returns the queries that differ."""
+    import os
+    import threading
+
+    T = max(1, min(16, len(os.sched_getaffinity(0))))
+    mp = orc.load_map(map_name)
+    which = list(which)
+    bad = []
+
+    def work(t):
+        o = orc.Oracle(orc.hot_path_params(**params_kw))
+        o.set_costmap(mp, build_table=True, nthreads=2)
+        for i in which[t::T]:
+            r, path, exp = o.plan(S[i], G[i])
+            if r.tobytes() != res[i].tobytes() or not np.array_equal(exp, got[i][1]) or path.tobytes() != got[i][0].tobytes():
+                bad.append(i)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return sorted(bad)
 
 
 @pytest.fixture(scope="module")
@@ -58,15 +88,13 @@ def test_maze_1024_queries_properties(maze_ctx, oracle_built):
     for k, i in enumerate(pick):
         assert res3[k].tobytes() == res[i].tobytes(), i
         assert np.array_equal(h.expanded(k), expanded[i]) and np.array_equal(h.path(k), paths[i])
-    # the oracle on a sample of the short queries (seconds on one core)
-    po = orc.hot_path_params()
-    o = orc.Oracle(po)
-    o.set_costmap(orc.load_map("map_maze"), build_table=True, nthreads=16)
-    short = [i for i in np.argsort(res["nodes_explored"]) if res[i]["nodes_explored"] > 5][:24]
-    for i in short:
-        r, path, exp = o.plan(S[i], G[i])
-        assert r.tobytes() == res[i].tobytes(), i
-        assert np.array_equal(exp, expanded[i]) and path.tobytes() == paths[i].tobytes()
+    # every one of the 1024 benchmark queries against the oracle (about a minute on sixteen cores)
+    bad = _compare_threaded("map_maze", {}, S, G, res, list(zip(paths, expanded)), range(1024))
+    assert not bad, bad
+    # ... which makes this batch's digest a verified answer: bench.py prints the digest of what its timed steps
+    # returned and compares it with the same file
+    want = json.loads((GOLDEN / "bench_digest.json").read_text())["queries_maze"]
+    assert result_digest(res) == want
 
 
 def test_footprint_10m_checks_against_oracle(oracle_built):
@@ -190,30 +218,11 @@ def test_full_depth_searches_match_oracle(maze_ctx, oracle_built):
     """Searches at the reference's full iteration limit (10 000), where one wrong verdict, cost bit or tie anywhere
     along the way changes everything after it: result records, expansion order and paths against the CPU oracle,
     one oracle context per thread."""
-    import os
-    import threading
-
     h = maze_ctx
     n = 96
     S, G = make_queries(h.collision, n, 4242, 50, 50)
     res = h.plan_batch(S, G)
     assert (res["nodes_expanded"] > 9000).sum() > 20  # many of them run to the limit
     got = [(h.path(i), h.expanded(i)) for i in range(n)]
-    T = max(1, min(16, len(os.sched_getaffinity(0))))
-    mp = orc.load_map("map_maze")
-    bad = []
-
-    def work(t):
-        o = orc.Oracle(orc.hot_path_params())
-        o.set_costmap(mp, build_table=True, nthreads=2)
-        for i in range(t, n, T):
-            r, path, exp = o.plan(S[i], G[i])
-            if r.tobytes() != res[i].tobytes() or not np.array_equal(exp, got[i][1]) or path.tobytes() != got[i][0].tobytes():
-                bad.append(i)
-
-    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
+    bad = _compare_threaded("map_maze", {}, S, G, res, got, range(n))
     assert not bad, sorted(bad)

@@ -179,6 +179,20 @@ def test_collision_footprint(parking):
     # ragged tail (n not a multiple of 4)
     for n in (1, 2, 3, 5, 7):
         assert np.array_equal(p.o.collision(xyt[:n], mode=1), p.h.collision(xyt[:n], mode=1))
+    # device buffers at any alignment: poses 4 bytes and verdicts 1 byte off a 16-byte boundary (hyas_collision_batch_dev)
+    import torch
+
+    n = 4099
+    buf = torch.zeros(3 * n + 8, dtype=torch.float32, device="cuda")
+    outb = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+    for off_in, off_out in ((0, 0), (1, 1), (3, 2), (2, 0), (0, 3)):
+        src = buf[off_in:off_in + 3 * n]
+        src.copy_(torch.from_numpy(xyt[:n].reshape(-1)))
+        dst = outb[off_out:off_out + n]
+        dst.zero_()
+        p.h.collision_dev(src.data_ptr(), 0, n, dst.data_ptr(), mode=hl.MODE_FOOTPRINT)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), a[:n]), (off_in, off_out)
 
 
 def test_table(parking):

@@ -365,3 +365,41 @@ def test_piecewise_bezier_path_shape(oracle_built):
         assert np.allclose(path[-1], g, atol=1e-5) and np.isfinite(path).all()
         assert hop.max() < hop0.max()
     assert hits >= 3
+
+
+def test_dubins_table_in_double_against_the_float_solver(ora):
+    """The Dubins heuristic table is OMPL's DubinsStateSpace::distance in double stored as float
+    (src/lookup_table.cpp:147-185); the analytic shot keeps the reference's own float solver (src/dubins.cpp).  Both solve
+    the same six words, so for every table entry the two lengths must agree to float rounding of the word sums (the float
+    solver carries a few ulp of error through its mod2pi and atan2 chain): this pins the double restatement against
+    arithmetic that IS pinned by the reference (the float solver reproduces src/dubins.cpp bit for bit), and records how
+    many entries differ in their last bits, which is what a float table would get wrong."""
+    o = orc.Oracle(orc.hot_path_params(curve_type=0, position_resolution=1, cd_min_turning_radius=6.0))
+    o.set_costmap(orc.load_map("map_parking"), build_table=False)
+    nx, ny, ns = o.table_dims()
+    tab = o.table_build(0, 0, ns)  # [ns][ny][nx], float
+    xs = np.arange(nx, dtype=np.float32)
+    ys = np.arange(ny, dtype=np.float32)
+    delta = np.float32(2 * math.pi / np.float32(72))
+    ts = [np.float32(0)]
+    while len(ts) < ns:
+        ts.append(np.float32(ts[-1] + delta))
+    differ = worst = total = 0
+    rng = np.random.default_rng(4)
+    picks = rng.permutation(nx * ny * ns)[:6000]
+    for e in picks:
+        k, j, i = int(e // (nx * ny)), int((e // nx) % ny), int(e % nx)
+        if i == 0 and j == 0:
+            continue
+        rc, out = o.dubins(np.zeros(3, np.float32), np.array([xs[i], ys[j], ts[k]], np.float32), 6.0)
+        assert rc == 0
+        f32 = np.float32(out[4])
+        f64 = np.float32(tab[k, j, i])
+        ulps = abs(int(f32.view(np.int32)) - int(f64.view(np.int32)))
+        total += 1
+        differ += ulps != 0
+        worst = max(worst, ulps)
+        assert ulps <= 64, (i, j, k, f32, f64)  # same word, same length up to the float chain's rounding
+    assert total > 5000
+    print(f"dubins table: {differ} of {total} sampled entries differ between the double and the float solver, at most {worst} ulp")
+    assert differ > 0  # if none differed the float solver would have been good enough
