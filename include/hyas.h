@@ -184,7 +184,7 @@ int hyas_collision_batch(hyas_ctx *ctx, int mode, const float *xyt, const float 
                          size_t n, uint8_t *free_out);
 /* The same on DEVICE buffers.  Any alignment a float / byte array may have is
  * accepted; mode FOOTPRINT runs its vectorised kernels when xyt_dev is 16-byte
- * and free_out_dev 4-byte aligned (what hipMalloc and torch give) and a
+ * and free_out_dev 4-byte aligned (what hipMalloc returns) and a
  * scalar-access kernel otherwise. */
 int hyas_collision_batch_dev(hyas_ctx *ctx, int mode, const float *xyt_dev,
                              const float *pred_xy_dev, size_t n, uint8_t *free_out_dev);
