@@ -34,7 +34,8 @@ extern "C" {
 #define HYAS_CURVE_BEZIER 2 /* cubic Bezier heuristic + shot (src/cubic_bezier.cpp, include/bezier.h) */
 
 #define HYAS_MAX_SUCC 8 /* most successors one node can generate (fixed steering set) */
-#define HYAS_ADAPTIVE_SLOTS 16 /* successor slots per node with adaptive_steering_angle_and_step_size; at most 15 are used */
+#define HYAS_ADAPTIVE_SLOTS 32 /* successor slots per node with adaptive_steering_angle_and_step_size: up to 31 forward
+                                * {step, steering} pairs and the reverse step */
 
 /* Planner parameters.  Field names, meaning and defaults follow
  * ParameterCollisionDetection and ParameterHybridAStar
@@ -118,7 +119,8 @@ typedef struct hyas_succ
 #define HYAS_STATUS_SHOT 2      /* analytic expansion connected */
 #define HYAS_STATUS_MAX_ITER 3  /* max_iterations reached: partial path */
 #define HYAS_STATUS_BAD_POSE 4  /* start or goal rejected (makePlan pre-check) */
-#define HYAS_STATUS_OVERFLOW 5  /* adaptive steering: a node produced more candidates than HYAS_ADAPTIVE_SLOTS - 2 */
+#define HYAS_STATUS_OVERFLOW 5  /* adaptive steering: a node produced more than HYAS_ADAPTIVE_SLOTS - 1 distinct {step, steering}
+                                 * pairs (pairs differ by a degree of steering at least; the in-tree maps stay at or below 20) */
 
 typedef struct hyas_result
 {
@@ -207,7 +209,7 @@ int hyas_expand_batch(hyas_ctx *ctx, const hyas_node *preds, const hyas_goal *go
  * adaptive_steering_angle_and_step_size the steering towards the goal is
  * weighted by the start-goal distance (CollisionDetection::FindStepSizeAndSteeringAngle,
  * src/collisiondetection.cpp:1383-1401).  hyas_expand_batch refuses that mode.
- * count[i] = 0xFF: node i produced more candidates than its slots hold. */
+ * count[i] = 0xFF: node i produced more than HYAS_ADAPTIVE_SLOTS - 1 distinct pairs. */
 int hyas_expand_batch_from(hyas_ctx *ctx, const hyas_node *preds, const hyas_goal *goals, const hyas_goal *starts,
                            const float *twod_cost, size_t n, hyas_succ *out, uint8_t *count);
 /* replaces: the per-costmap maps of the adaptive modes, CollisionDetection::SetMinDistanceMap,

@@ -66,7 +66,7 @@ SUCC_DT = np.dtype([("x", "f4"), ("y", "f4"), ("t", "f4"), ("g", "f4"), ("h", "f
 RESULT_DT = np.dtype([("status", "i4"), ("nodes_explored", "i4"), ("nodes_expanded", "i4"), ("successors", "i4"),
                       ("path_len", "i4"), ("g_final", "f4"), ("shot_length", "f4"), ("path_length", "f4")])
 
-STATUS_NO_PATH, STATUS_GOAL, STATUS_SHOT, STATUS_MAX_ITER, STATUS_BAD_POSE = range(5)
+STATUS_NO_PATH, STATUS_GOAL, STATUS_SHOT, STATUS_MAX_ITER, STATUS_BAD_POSE, STATUS_OVERFLOW = range(6)
 # return codes of include/hyas.h
 OK, EINVAL, ENOMEM, ENODEV, ESTATE, ERANGE = 0, -22, -12, -19, -1, -34
 MODE_POLYGON, MODE_FOOTPRINT = 0, 1

@@ -211,8 +211,10 @@ HD float closest_to_free_range(const DevMap &m, const Cell &c, float angle1, flo
     return d1 > d2 ? angle2 : angle1;
 }
 
-// Most pairs of one node, the reverse pair not counted: with it a node fills 14 of its HYAS_ADAPTIVE_SLOTS.
-#define HYAS_AD_MAX_PAIRS 13
+// Most pairs of one node, the reverse pair not counted: with it a node fills its HYAS_ADAPTIVE_SLOTS.  (Two pairs differ
+// by a degree of steering at least and most steering angles are kept within +-30 degrees; the in-tree maps give at most
+// 20 pairs with the 5-degree fans of fixed_number_of_steering_angle_in_free_angle_range = 0, 7 with the defaults.)
+#define HYAS_AD_MAX_PAIRS (HYAS_ADAPTIVE_SLOTS - 1)
 struct Pairs
 {
     float *step, *steer; // HYAS_AD_MAX_PAIRS entries each, the caller's (workgroup memory on the device)

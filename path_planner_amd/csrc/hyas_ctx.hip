@@ -1433,8 +1433,7 @@ static int run_step(hyas_ctx *c, const hyas_node *nodes, const hyas_goal *goals,
     if (count)
         for (size_t i = 0; i < n; ++i)
         {
-            const uint8_t v = ((const uint8_t *)(hs + o_cnt))[i];
-            count[i] = v == 0xFF ? v : (v & 15);
+            count[i] = ((const uint8_t *)(hs + o_cnt))[i];
         }
     if (ok)
         std::memcpy(ok, hs + o_ok, n);

@@ -965,9 +965,9 @@ __device__ __forceinline__ StepQuads stage_quads(const DevMap &m, Quad *s_quads,
 }
 
 // ADAPT: 0 fixed motion set, 1 adaptive steering angle and step size, 2 adaptive step size (hyas_adaptive.h).
-// With ADAPT == 1 a node has up to HYAS_AD_MAX_PAIRS + 1 candidates: sixteen lanes per node and test, eight nodes per
-// workgroup; the first lane of a node forms the node's {step, steering} list in workgroup memory, then the lanes take
-// one pair each.  count = 0xFF marks a node whose list did not fit.
+// With ADAPT == 1 a node has up to HYAS_AD_MAX_PAIRS + 1 candidates: sixteen candidate lanes per node and test, two nodes
+// per workgroup; the first lane of a node forms the node's {step, steering} list in workgroup memory, then the lanes take
+// one pair each, sixteen pairs per pass.  count = 0xFF marks a node whose list did not fit HYAS_AD_MAX_PAIRS.
 // Four lanes (eight with adaptive step size) share each candidate's test: a wave lasts as long as the longest obstacle
 // list among its lanes, and the lists are walked entry by entry, so each of the lanes takes every fourth (eighth)
 // entry (the verdict is an AND over the list).  Without list walks the successor kernel takes 19 us, with them
@@ -1064,147 +1064,173 @@ __device__ __forceinline__ void expand_role(const DevMap &m, const StepIn *__res
             s_pairs[local] = p.overflow ? -1 : p.n;
         }
     }
+    // With adaptive steering a node may have more candidates than it has lanes of a kind: they are taken CAND at a time
+    // (one pass is the rule: the reference's default switches give at most 7, the 5-degree fans of
+    // fixed_number_of_steering_angle_in_free_angle_range = 0 up to about 20).  Every workgroup makes as many passes as
+    // its longest list needs.
+    __shared__ int s_passes;
+    if (tid == 0)
+        s_passes = 1;
     __syncthreads(); // quads staged, pair lists formed
-    bool part_ok = false, evaluated = false, overflow = false;
-    float sx = 0, sy = 0, st = 0;
-    int prim = 0;
-    float s_g = 0, beat = INFINITY; // the successor's cost, and what it has to beat to be of use to the search
-    int s_idx = 0;
-    if (live)
+    int np = 0;      // the node's pairs (adaptive steering), the reverse pair not counted
+    bool overflow = false;
+    const bool reverse_pair = ADAPT == 1 && m.succ_reverse[m.n_succ - 1] != 0;
+    if (ADAPT == 1)
     {
-        // this lane's candidate: {step, steering angle}
-        bool have = false;
-        float first = 0, steer = 0;
-        if (ADAPT == 1)
-        {
-            const int np = s_pairs[local];
-            overflow = np < 0;
-            const bool reverse = m.succ_reverse[m.n_succ - 1] != 0;
-            if (!overflow && sl < np)
-                have = true, first = s_step[local][sl], steer = s_steer[local][sl];
-            else if (!overflow && sl == np && reverse) // the reverse pair follows the node's list (src/hybrid_a_star.cpp:629-654)
-                have = true, first = motion_step(true, dist), steer = m.succ_steer[m.n_succ - 1];
-        }
-        else if (sl < m.n_succ)
-        {
-            have = true, steer = m.succ_steer[sl];
-            const bool rev = m.succ_reverse[sl] != 0;
-            if (ADAPT == 2 && !rev) // src/hybrid_a_star.cpp:585-599
-                first = ad::find_step_size(m, cell, node.t, steer, dist, m.res_f);
-            else
-                first = motion_step(rev, dist);
-        }
-        if (have && successor_from_pair(node.x, node.y, node.t, first, steer, sx, sy, st, prim))
-        {
-            evaluated = true;
-            if (seg_lane && part == 0)
-            {
-                // cost and cell of the lane that writes the record; the cell's bound is requested here and used
-                // after the list walks
-                s_g = cost_so_far(m, node.g, normf(sub(f2(sx, sy), f2(node.x, node.y))), prim, node.prim);
-                s_idx = idx_3d(m, sx, sy, st);
-                if (bound && s_idx >= 0 && (uint32_t)s_idx < bound_cells)
-                    beat = __int_as_float(__builtin_nontemporal_load(bound + (size_t)node.query * bound_cells + (uint32_t)s_idx));
-            }
-            if (pose_lane)
-                part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st, (uint32_t)part, (uint32_t)SUB);
-            else
-                part_ok = segment_free(m, sq, sx, sy, node.x, node.y, (uint32_t)part, (uint32_t)SUB);
-        }
+        np = s_pairs[local];
+        overflow = np < 0;
+        const int total = (!live || overflow) ? 0 : np + (reverse_pair ? 1 : 0);
+        if (nl == 0 && pose_lane && total > CAND)
+            atomicMax(&s_passes, (total + CAND - 1) / CAND);
+        __syncthreads();
     }
-    if (SUB > 1) // a candidate is free iff every part of its list says so
-    {
-#pragma unroll
-        for (int o = CAND; o < LANES; o <<= 1)
-            part_ok = (__shfl_xor(part_ok ? 1 : 0, o, 64) != 0) && part_ok;
-    }
-    if (pose_lane)
-        s_pose[tid] = part_ok ? 1 : 0;
-    __syncthreads();
-    // (s_g >= beat is false for a NaN cost: such a successor is left to the host)
-    const bool ok = seg_lane && part == 0 && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0 && !(s_g >= beat);
-    hyas_succ s;
-    if (ok)
-    {
-        s.x = sx, s.y = sy, s.t = st;
-        s.g = s_g;
-        s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
-        s.idx = s_idx;
-        s.prim = (int8_t)prim;
-        s.free = 1;
-        // search rounds: which entry of the motion set this successor comes from (1-based, high byte)
-        s.pad = (flags & ROUND_TAG_CANDIDATE) ? (uint16_t)((sl + 1) << 8) : (uint16_t)0;
-    }
-    // compact in candidate order, as the reference's output vector
+    const int n_passes = ADAPT == 1 ? s_passes : 1;
     const unsigned grp = (lane / LANES) * LANES; // the node's part 0 lanes: grp .. grp + CAND - 1
     constexpr unsigned long long GROUP = (1ull << CAND) - 1ull;
-    const unsigned mask = (unsigned)((__ballot(ok) >> grp) & GROUP);
-    const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & GROUP);
-    if (child)
-    {
-        // The successor with the lowest f = g + h (the earliest of equals: the one the open list would pop first)
-        // becomes node `slot` of the next, deeper launch; its record carries bit 0 of pad so that the host knows which
-        // one was taken without redoing the comparison.
-        float bf = ok ? s.g + s.h : INFINITY;
-        if (!(bf == bf))
-            bf = INFINITY;
-        int bi = ok ? sl : 255;
-        for (int off = CAND / 2; off > 0; off >>= 1)
-        {
-            const float of = __shfl_xor(bf, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (of < bf || (of == bf && oi < bi))
-                bf = of, bi = oi;
-        }
-        if (ok && bi == sl)
-        {
-            s.pad |= 1;
-            child[slot] = StepIn{s.x, s.y, s.t, s.g, prim, node.query, flags & ROUND_CHILD_SHOOT, node.pad};
-        }
-        if (in_launch && seg_lane && sl == 0 && part == 0 && bi == 255) // nothing to expand one level down
-            child[slot] = StepIn{node.x, node.y, node.t, node.g, node.prim, node.query, STEP_DEAD, node.pad};
-    }
-    if (ok)
-    {
-        int pos = __popc(mask & ((1u << sl) - 1u));
-        if (ro.base)
-        {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 *unit = reinterpret_cast<u32x4 *>(ro.base) + (size_t)slot * ro.units + 2 + 2 * pos;
-            const u32x4 a = {__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.t),
-                             ro.tag << 9 | (uint32_t)(s.pad & 1u) << 8 | (uint32_t)(s.pad >> 8) << 3 | (uint32_t)prim};
-            const u32x4 b = {__float_as_uint(s.g), __float_as_uint(s.h), (uint32_t)s.idx, ro.tag};
-            __builtin_nontemporal_store(a, unit);
-            __builtin_nontemporal_store(b, unit + 1);
-        }
-        else
-            succ[(size_t)slot * m.n_slots + pos] = s;
-    }
     const bool writer = in_launch && seg_lane && sl == 0 && part == 0;
-    if (writer) // low nibble: emitted successors, high nibble: candidates that got a verdict
+    int emitted = 0, verdicts = 0; // of the node, over the passes so far
+    uint32_t walked_all = 0;
+    for (int pass = 0; pass < n_passes; ++pass)
     {
-        const uint8_t cnt = overflow ? (uint8_t)0xFF : (uint8_t)(__popc(mask) | (__popc(emask) << 4));
+        const int ci = pass * CAND + sl; // this lane's candidate
+        bool part_ok = false, evaluated = false;
+        float sx = 0, sy = 0, st = 0;
+        int prim = 0;
+        float s_g = 0, beat = INFINITY; // the successor's cost, and what it has to beat to be of use to the search
+        int s_idx = 0;
+        if (live)
+        {
+            // this lane's candidate: {step, steering angle}
+            bool have = false;
+            float first = 0, steer = 0;
+            if (ADAPT == 1)
+            {
+                if (!overflow && ci < np)
+                    have = true, first = s_step[local][ci], steer = s_steer[local][ci];
+                else if (!overflow && ci == np && reverse_pair) // the reverse pair follows the node's list (src/hybrid_a_star.cpp:629-654)
+                    have = true, first = motion_step(true, dist), steer = m.succ_steer[m.n_succ - 1];
+            }
+            else if (sl < m.n_succ)
+            {
+                have = true, steer = m.succ_steer[sl];
+                const bool rev = m.succ_reverse[sl] != 0;
+                if (ADAPT == 2 && !rev) // src/hybrid_a_star.cpp:585-599
+                    first = ad::find_step_size(m, cell, node.t, steer, dist, m.res_f);
+                else
+                    first = motion_step(rev, dist);
+            }
+            if (have && successor_from_pair(node.x, node.y, node.t, first, steer, sx, sy, st, prim))
+            {
+                evaluated = true;
+                if (seg_lane && part == 0)
+                {
+                    // cost and cell of the lane that writes the record; the cell's bound is requested here and used
+                    // after the list walks
+                    s_g = cost_so_far(m, node.g, normf(sub(f2(sx, sy), f2(node.x, node.y))), prim, node.prim);
+                    s_idx = idx_3d(m, sx, sy, st);
+                    if (bound && s_idx >= 0 && (uint32_t)s_idx < bound_cells)
+                        beat = __int_as_float(__builtin_nontemporal_load(bound + (size_t)node.query * bound_cells + (uint32_t)s_idx));
+                }
+                if (pose_lane)
+                    part_ok = on_grid(m, sx, sy) && pose_free(m, sq, sx, sy, st, (uint32_t)part, (uint32_t)SUB);
+                else
+                    part_ok = segment_free(m, sq, sx, sy, node.x, node.y, (uint32_t)part, (uint32_t)SUB);
+            }
+        }
+        if (SUB > 1) // a candidate is free iff every part of its list says so
+        {
+#pragma unroll
+            for (int o = CAND; o < LANES; o <<= 1)
+                part_ok = (__shfl_xor(part_ok ? 1 : 0, o, 64) != 0) && part_ok;
+        }
+        if (pass)
+            __syncthreads(); // the pass before has read its pose verdicts
+        if (pose_lane)
+            s_pose[tid] = part_ok ? 1 : 0;
+        __syncthreads();
+        // (s_g >= beat is false for a NaN cost: such a successor is left to the host)
+        const bool ok = seg_lane && part == 0 && evaluated && part_ok && s_pose[tid & (EXPAND_THREADS / 2 - 1)] != 0 && !(s_g >= beat);
+        hyas_succ s;
+        if (ok)
+        {
+            s.x = sx, s.y = sy, s.t = st;
+            s.g = s_g;
+            s.h = heuristic(m, sx, sy, st, goal.x, goal.y, goal.t, my_twod);
+            s.idx = s_idx;
+            s.prim = (int8_t)prim;
+            s.free = 1;
+            // search rounds: which entry of the motion set this successor comes from (1-based, high byte; fixed motion set)
+            s.pad = (flags & ROUND_TAG_CANDIDATE) ? (uint16_t)(((ci + 1) & 31) << 8) : (uint16_t)0;
+        }
+        // compact in candidate order, as the reference's output vector
+        const unsigned mask = (unsigned)((__ballot(ok) >> grp) & GROUP);
+        const unsigned emask = (unsigned)((__ballot(seg_lane && evaluated) >> grp) & GROUP);
+        if (child && pass == 0)
+        {
+            // The successor with the lowest f = g + h (the earliest of equals: the one the open list would pop first; of
+            // the first pass, where there are several) becomes node `slot` of the next, deeper launch; its record carries
+            // bit 0 of pad so that the host knows which one was taken without redoing the comparison.
+            float bf = ok ? s.g + s.h : INFINITY;
+            if (!(bf == bf))
+                bf = INFINITY;
+            int bi = ok ? sl : 255;
+            for (int off = CAND / 2; off > 0; off >>= 1)
+            {
+                const float of = __shfl_xor(bf, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (of < bf || (of == bf && oi < bi))
+                    bf = of, bi = oi;
+            }
+            if (ok && bi == sl)
+            {
+                s.pad |= 1;
+                child[slot] = StepIn{s.x, s.y, s.t, s.g, prim, node.query, flags & ROUND_CHILD_SHOOT, node.pad};
+            }
+            if (in_launch && seg_lane && sl == 0 && part == 0 && bi == 255) // nothing to expand one level down
+                child[slot] = StepIn{node.x, node.y, node.t, node.g, node.prim, node.query, STEP_DEAD, node.pad};
+        }
+        if (ok)
+        {
+            const int pos = emitted + __popc(mask & ((1u << sl) - 1u));
+            if (ro.base)
+            {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 *unit = reinterpret_cast<u32x4 *>(ro.base) + (size_t)slot * ro.units + 2 + 2 * pos;
+                const u32x4 a = {__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.t),
+                                 ro.tag << 9 | (uint32_t)(s.pad & 1u) << 8 | (uint32_t)(s.pad >> 8) << 3 | (uint32_t)prim};
+                const u32x4 b = {__float_as_uint(s.g), __float_as_uint(s.h), (uint32_t)s.idx, ro.tag};
+                __builtin_nontemporal_store(a, unit);
+                __builtin_nontemporal_store(b, unit + 1);
+            }
+            else
+                succ[(size_t)slot * m.n_slots + pos] = s;
+        }
+        emitted += __popc(mask), verdicts += __popc(emask);
+        if (MODE == 1)
+        {
+            uint32_t walked = (seg_lane && evaluated && part == 0) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
+            for (int off = CAND / 2; off > 0; off >>= 1)
+                walked += __shfl_xor(walked, off, 64);
+            walked_all += walked;
+        }
+    }
+    if (writer) // successors emitted, candidates that got a verdict; 0xFF: more pairs than a node's list holds
+    {
         if (ro.base)
         {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 e = {(uint32_t)cnt, 0u, 0u, ro.tag};
+            const u32x4 e = {overflow ? 0xFFu : (uint32_t)emitted | (uint32_t)verdicts << 8, 0u, 0u, ro.tag};
             __builtin_nontemporal_store(e, reinterpret_cast<u32x4 *>(ro.base) + (size_t)slot * ro.units + 1);
         }
         else
-            count[slot] = cnt;
+            count[slot] = overflow ? (uint8_t)0xFF : (uint8_t)emitted;
     }
-    if (MODE == 1)
+    if (MODE == 1 && writer && live)
     {
-        uint32_t walked = (seg_lane && evaluated && part == 0) ? lists_walked(m, sx, sy, st, node.x, node.y) : 0;
-        for (int off = CAND / 2; off > 0; off >>= 1)
-            walked += __shfl_xor(walked, off, 64);
-        if (writer && live)
-        {
-            atomicAdd(&stats[3], (unsigned long long)__popc(emask));
-            atomicAdd(&stats[4], (unsigned long long)walked);
-            atomicAdd(&stats[5], (unsigned long long)__popc(mask));
-            atomicAdd(&stats[6], 1ull);
-        }
+        atomicAdd(&stats[3], (unsigned long long)verdicts);
+        atomicAdd(&stats[4], (unsigned long long)walked_all);
+        atomicAdd(&stats[5], (unsigned long long)emitted);
+        atomicAdd(&stats[6], 1ull);
     }
 }
 

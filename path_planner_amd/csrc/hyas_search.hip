@@ -447,7 +447,8 @@ struct Driver
         int cand[HYAS_MAX_NODES];
         int32_t id[HYAS_MAX_NODES];
     };
-    void consume(Query &q, uint8_t shot_ok, float shot_len, uint8_t count, const hyas_succ *succ, int32_t *best_child = nullptr,
+    // count: successors emitted | candidates that received a verdict << 8; 0xFF: the node's pair list overflowed
+    void consume(Query &q, uint8_t shot_ok, float shot_len, uint32_t count, const hyas_succ *succ, int32_t *best_child = nullptr,
                  Wanted *wanted = nullptr, UpdSink *upd = nullptr)
     {
         const int32_t pid = q.cur;
@@ -461,18 +462,18 @@ struct Driver
             return;
         }
         const SNode pred = q.arena[pid];
-        if (count == 0xFF) // more steering candidates than a node's slots hold (adaptive mode)
+        if ((count & 0xFFu) == 0xFFu) // more distinct steering candidates than a node's list holds (adaptive mode)
         {
             q.res.status = HYAS_STATUS_OVERFLOW;
             q.done = true;
             return;
         }
-        q.res.successors += count >> 4; // motion-set entries that received a verdict
-        count &= 15;
+        q.res.successors += (int32_t)(count >> 8 & 0xFFu); // motion-set entries that received a verdict
+        const int n_rec = (int)(count & 0xFFu);
         // the lookups below miss the cache independently of each other: request all their lines first
         {
             const size_t cmask = q.cells.slots.size() - 1;
-            for (int k = 0; k < count; ++k)
+            for (int k = 0; k < n_rec; ++k)
             {
                 const hyas_succ &s = succ[k];
                 __builtin_prefetch(&q.cells.slots[q.cells.hash(s.idx) & cmask]);
@@ -481,14 +482,14 @@ struct Driver
         // the successor the kernel has sent on to the next, deeper launch of this round (marked pad = 1)
         int kmin = -1;
         if (best_child)
-            for (int k = 0; k < count; ++k)
+            for (int k = 0; k < n_rec; ++k)
                 if (succ[k].pad & 1)
                     kmin = k;
         // The reference tests, in this order: duplicate of an open-list entry, cell closed, not better than the cell's
         // g, same cell as the predecessor and beyond the tie breaker (:255-283).  Each of them only drops the
         // successor, so their order does not matter: the cell tests come first here because they are cheaper and
         // drop most successors, and the duplicate check (a walk over neighbouring open-list entries) runs for the rest.
-        for (int k = 0; k < count; ++k)
+        for (int k = 0; k < n_rec; ++k)
         {
             const hyas_succ &s = succ[k];
             const uint64_t p0 = probe_on ? __builtin_ia32_rdtsc() : 0;
@@ -1355,8 +1356,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             hyas_succ got[HYAS_ADAPTIVE_SLOTS];
                             if (!unit(blk + 16, read_tag, 0, w))
                                 return;
-                            const uint8_t cnt = (uint8_t)w[0];
-                            const int n_got = cnt == 0xFF ? 0 : (cnt & 15);
+                            const uint32_t cnt = w[0];
+                            const int n_got = (cnt & 0xFFu) == 0xFFu ? 0 : (int)std::min<uint32_t>(cnt & 0xFFu, HYAS_ADAPTIVE_SLOTS);
                             for (int j = 0; j < n_got; ++j)
                             {
                                 if (!unit(blk + 32 + 32 * j, read_tag, 9, w) || !unit(blk + 48 + 32 * j, read_tag, 0, wb))

@@ -75,25 +75,28 @@ def test_expand_combined_mode(oracle_built, flags):
               steering_angle_towards_free_angle_range_for_obstacle_angle_range=(flags >> 2) & 1,
               fixed_number_of_steering_angle_in_free_angle_range=(flags >> 3) & 1)
     p = Pair("map_maze", position_resolution=1, **COMBINED, **kw)
-    assert p.h.num_successors() == 16 == p.o.num_successors()
+    assert p.h.num_successors() == 32 == p.o.num_successors()
     nodes, goals = _nodes(p, 3000, 40 + flags)
     starts = _starts(p, 3000, 90 + flags)
-    # more than 13 forward candidates do not fit a node's slots: flagged, never silently cut (the reference's default
-    # switches stay far below that; the 5-degree fans of fixed_number... = 0 can exceed it)
-    over = np.array([p.o.step_steer_pairs((nd["x"], nd["y"], nd["t"]), (g["x"], g["y"], g["t"]), (s["x"], s["y"], s["t"]))[1] - 1 > 13
-                     for nd, g, s in zip(nodes, goals, starts)])
-    if flags == 0b1101:
-        assert not over.any()
-    fits = np.flatnonzero(~over)[:48]
-    twod = np.stack([p.o.flood((g["x"], g["y"], g["t"])) for g in goals[fits]])
-    a, ca = p.o.expand(nodes[fits], goals[fits], twod, starts[fits])
-    b, cb = p.h.expand(nodes[fits], goals[fits], twod, starts[fits])
+    # a node holds up to 31 forward {step, steering} pairs and the reverse step (two passes of sixteen candidates on the
+    # GPU): the reference's default switches give at most 7, the 5-degree fans of fixed_number... = 0 about 20
+    n_pairs = np.array([p.o.step_steer_pairs((nd["x"], nd["y"], nd["t"]), (g["x"], g["y"], g["t"]), (s["x"], s["y"], s["t"]))[1]
+                        for nd, g, s in zip(nodes, goals, starts)])
+    assert n_pairs.max() <= 32
+    if flags == 0:
+        assert (n_pairs > 16).sum() > 50  # nodes that need the second pass are in the sample
+    if not flags & 0b1000:
+        assert (n_pairs > 14).sum() > 5  # ... and in the other fan configurations nodes beyond the former limit
+    some = np.concatenate([np.flatnonzero(n_pairs > 16)[:24], np.arange(48)])
+    twod = np.stack([p.o.flood((g["x"], g["y"], g["t"])) for g in goals[some]])
+    a, ca = p.o.expand(nodes[some], goals[some], twod, starts[some])
+    b, cb = p.h.expand(nodes[some], goals[some], twod, starts[some])
     assert np.array_equal(ca, cb) and a.tobytes() == b.tobytes()
     a, ca = p.o.expand(nodes, goals, None, starts)
     b, cb = p.h.expand(nodes, goals, None, starts)
-    assert np.array_equal(cb[over], np.full(over.sum(), 0xFF, np.uint8))
-    assert np.array_equal(ca[~over], cb[~over])
-    assert a[~over].tobytes() == b[~over].tobytes()
+    assert not (cb == 0xFF).any()  # nothing flagged
+    assert np.array_equal(ca, cb)
+    assert a.tobytes() == b.tobytes()
     assert ca.max() >= 3 and (ca == 0).sum() < len(ca) // 2
     # the plain entry point has no start pose to weigh with
     with pytest.raises(hl.HyasError):
@@ -118,6 +121,18 @@ def test_plan_adaptive_modes(maze_combined, parking_step, oracle_built):
         s, g = p.free_poses(n, seed), p.free_poses(n, seed + 1)
         res = _plan_compare(p, s, g)
         assert len(set(res["status"].tolist())) >= 2
+
+
+def test_plan_with_steering_fans(oracle_built):
+    """Whole searches with fixed_number_of_steering_angle_in_free_angle_range = 0 (a free angle range is covered by a fan of
+    steering angles 5 degrees apart, src/collisiondetection.cpp:836-900): nodes with more than sixteen candidates take two
+    passes on the GPU; nothing is flagged, and records, expansion order and paths equal the oracle's."""
+    for mp, n, kw in (("map_maze", 32, {}), ("map_parking", 24, dict(add_one_more_successor=0))):
+        p = Pair(mp, position_resolution=1, max_iterations=400, fixed_number_of_steering_angle_in_free_angle_range=0, **COMBINED, **kw)
+        s, g = p.free_poses(n, 81), p.free_poses(n, 82)
+        res = _plan_compare(p, s, g)
+        assert not (res["status"] == hl.STATUS_OVERFLOW).any()
+        assert res["nodes_expanded"].sum() > (1000 if mp == "map_maze" else 50)
 
 
 def test_reference_defaults_plan(oracle_built):
