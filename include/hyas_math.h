@@ -189,30 +189,10 @@ HY_HD void hy_sincos(double x, double *s, double *c)
 /* ---- atan / atan2 / asin / acos ---------------------------------------- */
 
 /* atan on [0, 1]: nearest table point c = i/4, then the odd Taylor series in
- * t = (x - c) / (1 + x c), |t| <= 0.125 -> truncation error < 1e-20. */
-HY_HD double hy_atan01(double x)
+ * t = (x - c) / (1 + x c), |t| <= 0.125 -> truncation error < 1e-20.
+ * hy_atan01_series: the part after the table point (c, hi = atan(c)) is chosen. */
+HY_HD double hy_atan01_series(double x, double c, double hi)
 {
-    int i = (int)(x * 4.0 + 0.5);
-    double c = 0.25 * (double)i;
-    double hi;
-    switch (i)
-    {
-    case 0:
-        hi = 0.0;
-        break;
-    case 1:
-        hi = 0.24497866312686414;
-        break;
-    case 2:
-        hi = 0.4636476090008061;
-        break;
-    case 3:
-        hi = 0.6435011087932844;
-        break;
-    default:
-        hi = 0.7853981633974483;
-        break;
-    }
     double t = (x - c) / (1.0 + x * c);
     double z = t * t;
     double p = 1.0 / 21.0;
@@ -228,13 +208,61 @@ HY_HD double hy_atan01(double x)
     return hi + (t + (t * z) * p);
 }
 
-/* atan of a non-negative finite or infinite argument. */
+HY_HD double hy_atan01(double x)
+{
+    int i = (int)(x * 4.0 + 0.5);
+    double c = 0.25 * (double)i;
+    /* atan(i/4), picked with selects: wide hardware runs every arm of a branch some lane takes */
+    const double lo01 = (i & 1) ? 0.24497866312686414 : 0.0, lo23 = (i & 1) ? 0.6435011087932844 : 0.4636476090008061;
+    const double hi = (i >= 4) ? 0.7853981633974483 : (i & 2) ? lo23 : lo01;
+    return hy_atan01_series(x, c, hi);
+}
+
+/* The same with atan(i/4) read from the caller's copy of HY_QUARTER_ATANS (eight entries, so that no index, not
+ * even that of a NaN, reads outside it): for kernels that keep the copy in fast local memory, one read instead
+ * of the chain of selects. */
+#define HY_QUARTER_ATANS                                                                                                  \
+    {                                                                                                                     \
+        0.0, 0.24497866312686414, 0.4636476090008061, 0.6435011087932844, 0.7853981633974483, 0.7853981633974483,          \
+            0.7853981633974483, 0.7853981633974483                                                                        \
+    }
+HY_HD double hy_atan01_q(double x, const double *quarter_atans)
+{
+    int i = (int)(x * 4.0 + 0.5);
+    return hy_atan01_series(x, 0.25 * (double)i, quarter_atans[i & 7]);
+}
+
+/* atan of a non-negative finite or infinite argument: one pass through the series for both halves, above 1
+ * through the reciprocal (0 for inf).  On the device the reciprocal stays inside its branch: lanes whose
+ * arguments are all at most 1 skip the division. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HY_KEEP_IN_BRANCH(v) asm volatile("" : "+v"(v))
+#else
+#define HY_KEEP_IN_BRANCH(v) (void)0
+#endif
 HY_HD double hy_atan_pos(double x)
 {
-    if (x <= 1.0)
-        return hy_atan01(x);
-    double inv = 1.0 / x; /* 0 for inf */
-    return (HY_PIO2 - hy_atan01(inv)) + HY_PIO2_LO;
+    const bool small = x <= 1.0;
+    double arg = x;
+    if (!small)
+    {
+        arg = 1.0 / x;
+        HY_KEEP_IN_BRANCH(arg);
+    }
+    const double a = hy_atan01(arg);
+    return small ? a : (HY_PIO2 - a) + HY_PIO2_LO;
+}
+HY_HD double hy_atan_pos_q(double x, const double *quarter_atans)
+{
+    const bool small = x <= 1.0;
+    double arg = x;
+    if (!small)
+    {
+        arg = 1.0 / x;
+        HY_KEEP_IN_BRANCH(arg);
+    }
+    const double a = hy_atan01_q(arg, quarter_atans);
+    return small ? a : (HY_PIO2 - a) + HY_PIO2_LO;
 }
 
 HY_HD double hy_copysign(double m, double s)
@@ -261,6 +289,26 @@ HY_HD_CALL double hy_atan2(double y, double x)
         a = (HY_PI - a) + HY_PI_LO;
     return hy_copysign(a, y);
 }
+/* hy_atan2 through hy_atan01_q */
+HY_HD double hy_atan2_q(double y, double x, const double *quarter_atans)
+{
+    if (hy_isnan(x) || hy_isnan(y))
+        return x + y;
+    bool xneg = __builtin_signbit(x);
+    if (y == 0.0)
+        return xneg ? hy_copysign(HY_PI, y) : y;
+    if (x == 0.0)
+        return hy_copysign(HY_PIO2, y);
+    double ax = hy_fabs(x), ay = hy_fabs(y);
+    double a;
+    if (ax > 1.7976931348623157e308 && ay > 1.7976931348623157e308)
+        a = 0.7853981633974483;
+    else
+        a = hy_atan_pos_q(ay / ax, quarter_atans);
+    if (xneg)
+        a = (HY_PI - a) + HY_PI_LO;
+    return hy_copysign(a, y);
+}
 
 HY_HD double hy_asin(double x)
 {
@@ -270,6 +318,14 @@ HY_HD double hy_asin(double x)
 HY_HD double hy_acos(double x)
 {
     return hy_atan2(hy_sqrt((1.0 - x) * (1.0 + x)), x);
+}
+HY_HD double hy_asin_q(double x, const double *quarter_atans)
+{
+    return hy_atan2_q(x, hy_sqrt((1.0 - x) * (1.0 + x)), quarter_atans);
+}
+HY_HD double hy_acos_q(double x, const double *quarter_atans)
+{
+    return hy_atan2_q(hy_sqrt((1.0 - x) * (1.0 + x)), x, quarter_atans);
 }
 
 /* ---- float forms: evaluate in double, round once ------------------------ */

@@ -591,12 +591,23 @@ __global__ void __launch_bounds__(256) k_min_distance(DevMap m, const float *__r
 
 // ------------------------------------------------------------ heuristic table
 // One table entry per thread (src/lookup_table.cpp:209-218): cost of the
-// Reeds-Shepp path from the origin to (xs[i], ys[j], ts[k]).
+// Reeds-Shepp path from the origin to (xs[i], ys[j], ts[k]).  The kernel is bound by the issue of its f64
+// arithmetic (no memory traffic to speak of), so it runs the length-only form of the solver (rs::shortest_length:
+// shared polar forms, candidates whose first arc is negative dropped before their arc tangents) with the arc
+// tangent's five table values in LDS; one entry per thread and many small workgroups, so that the tail of the launch
+// is one workgroup's time.
 __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, uint32_t nx,
                                                   const float *__restrict__ ys, uint32_t ny,
                                                   const float *__restrict__ ts, uint32_t k0, uint32_t k1, double rho,
                                                   float *__restrict__ out)
 {
+    __shared__ double s_quarter_atans[8];
+    {
+        const double qa[8] = HY_QUARTER_ATANS;
+        if (threadIdx.x < 8)
+            s_quarter_atans[threadIdx.x] = qa[threadIdx.x];
+        __syncthreads();
+    }
     const size_t total = (size_t)(k1 - k0) * ny * nx;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
     {
@@ -607,7 +618,7 @@ __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, 
         const double q1[3] = {(double)xs[i], (double)ys[j], (double)ts[k]};
         double x, y, phi;
         rs::normalise(q0, q1, rho, x, y, phi);
-        out[e] = (float)(rho * rs::solve_hoisted(x, y, phi).total);
+        out[e] = (float)(rho * rs::shortest_length(x, y, phi, s_quarter_atans));
     }
 }
 
@@ -2291,7 +2302,8 @@ void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny,
     size_t total = (size_t)(k1 - k0) * ny * nx;
     if (total == 0)
         return;
-    hipLaunchKernelGGL(k_table_rs, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_table_rs, dim3((uint32_t)(blocks < (1u << 30) ? blocks : (1u << 30))), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
 }
 
 void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,

@@ -577,6 +577,221 @@ RS_HD Path solve_hoisted(double x, double y, double phi)
     return best;
 }
 
+// ---- length of the shortest path only: what the heuristic table stores ------------------------------------------
+// The 44 candidates regrouped by symmetry instead of by family, so that what candidates of one symmetry share is
+// formed once: five closed forms start from the polar form of (x - sin phi, y - 1 + cos phi) and six from that of
+// (x + sin phi, y - 1 - cos phi), in the forward or the backwards frame, and two of them take the same second square
+// root.  Every candidate that can be valid still performs the operations of base_formula_body_sc() and
+// candidate_tail() on the same values in the same order, so its lengths are equal bit for bit; the families' scans
+// are replaced by a per-family minimum that remembers the candidate's position in the reference order (first of
+// equals wins, as a strict "shorter than" scan does), and the families are then combined in their order with the
+// bounds of family_bound().
+// A candidate is dropped before its arc tangents where the signs of their arguments already say that its first arc
+// t comes out below -RS_ZERO, which the closed form rejects: atan2(y, x) has the sign of y, and for y < 0 it is
+// below -RS_DEAD unless x > 0 and -y <= RS_DEAD x.  RS_DEAD is several times RS_ZERO plus the rounding of the sums
+// involved, so that only candidates the closed form rejects are dropped.
+#define RS_DEAD 1e-14
+
+// v with its sign bit flipped where `mask` has it set
+RS_HD double flip_sign(double v, unsigned long long mask)
+{
+    unsigned long long b;
+    __builtin_memcpy(&b, &v, 8);
+    b ^= mask;
+    __builtin_memcpy(&v, &b, 8);
+    return v;
+}
+
+// mod2pi() for sums of a few angles: fmod's long division by 2 pi written out for |x| < 8 pi.  Each subtraction
+// is exact (the minuend lies within a factor two of the subtrahend), so the remainder is fmod's, bit for bit; the
+// fold into [-pi, pi] works on the magnitude (a - b == -(b - a) in IEEE arithmetic) and the sign of x goes on last,
+// zero included, as fmod's does.  Anything else (NaN included) sets `beyond`, and the caller falls back on the
+// general form.
+RS_HD double mod2pi_few_turns(double x, bool &beyond)
+{
+    const double T = 2. * RS_PI;
+    double ax = hy_fabs(x);
+    beyond = beyond || !(ax < 4. * T);
+    if (ax >= 2. * T) // seldom: a branch of its own, which lanes skip together
+    {
+        ax = ax - 2. * T;
+        HY_KEEP_IN_BRANCH(ax);
+    }
+    ax = (ax >= T) ? ax - T : ax;
+    ax = (ax > RS_PI) ? ax - T : ax;
+    unsigned long long xbits;
+    __builtin_memcpy(&xbits, &x, 8);
+    return flip_sign(ax, xbits & 0x8000000000000000ull);
+}
+
+// tau_omega(u, v, ...) for v == -u (same == false) or v == u (same == true), the two uses there are (:229-260):
+// cos(v) is cos(u) either way (hy_cos is even bit for bit: the reduction and both kernels are), and for v == u
+// delta is mod2pi(u - u) = 0 with sine 0 and cosine 1.
+RS_HD void tau_omega_pm(double u, bool same, double xi, double eta, double phi, double &tau, double &omega, bool &beyond, const double *qa)
+{
+    double su, cu, sd = 0., cd = 1.;
+    hy_sincos(u, &su, &cu);
+    const double v = same ? u : -u;
+    if (!same)
+        hy_sincos(mod2pi_few_turns(u - v, beyond), &sd, &cd);
+    const double A = su - sd, B = cu - cd - 1.;
+    const double t1 = hy_atan2_q(eta * A - xi * B, xi * A + eta * B, qa), t2 = 2. * (cd - cu - cu) + 3;
+    tau = mod2pi_few_turns((t2 < 0) ? t1 + RS_PI : t1, beyond);
+    omega = mod2pi_few_turns(tau - u + v - phi, beyond);
+}
+
+struct FamilyBest
+{
+    double l, total; // the length the family compares, and the path's length
+    int at;          // candidate number
+};
+RS_HD void offer(FamilyBest &b, bool ok, int c, double L, double total)
+{
+    const bool take = ok && (L < b.l || (L == b.l && c < b.at));
+    b.l = take ? L : b.l;
+    b.total = take ? total : b.total;
+    b.at = take ? c : b.at;
+}
+// atan2(y, x) is certainly below -RS_ZERO
+RS_HD bool angle_is_negative(double y, double x) { return y < 0. && !(-y <= RS_DEAD * x); }
+
+// The candidates of symmetry s in one frame, (X, Y) being the goal there with the symmetry's signs applied.
+template <bool BACK>
+RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, double cp, FamilyBest *fam, bool &beyond, const double *qa)
+{
+    const double hp = .5 * RS_PI;
+    {
+        // forms on (x - sin phi, y - 1 + cos phi): (8.1) forward only, (8.3/8.4) and (8.9) in both frames
+        const double xi = ax - sp, eta = ay - 1. + cp;
+        const double R = hy_sqrt(xi * xi + eta * eta), TH = hy_atan2_q(eta, xi, qa);
+        if (!BACK) // LpSpLp, group 0
+        {
+            const double t = TH, u = R;
+            const double v = mod2pi_few_turns(aphi - t, beyond);
+            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+            offer(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, 0 + s, L, L);
+        }
+        if (R <= 4.) // LpRmL, groups 2 and 3
+        {
+            const double u = -2. * hy_asin_q(.25 * R, qa);
+            const double t = mod2pi_few_turns(TH + .5 * u + RS_PI, beyond);
+            const double v = mod2pi_few_turns(aphi - t + u, beyond);
+            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+            const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hy_fabs(t) : L;
+            offer(fam[1], t >= -RS_ZERO && u <= RS_ZERO, (BACK ? 12 : 8) + s, L, total);
+        }
+        // LpRmSmLm, groups 6 and 8: t = mod2pi(TH + a) with a = atan2(r, -2) in [pi/2, pi]; for TH inside
+        // (pi/2, pi) the sum lies inside (pi, 2 pi) and t inside (-pi, 0)
+        if (R >= 2. && !(TH > hp + RS_DEAD && TH < RS_PI - RS_DEAD))
+        {
+            const double r = hy_sqrt(R * R - 4.);
+            const double u = 2. - r;
+            const double t = mod2pi_few_turns(TH + hy_atan2_q(r, -2., qa), beyond);
+            const double v = mod2pi_few_turns(aphi - .5 * RS_PI - t, beyond);
+            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+            const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hp + hy_fabs(t) : hy_fabs(t) + hp + hy_fabs(u) + hy_fabs(v);
+            offer(fam[3], t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO, (BACK ? 32 : 24) + s, L, total);
+        }
+    }
+    {
+        // forms on (x + sin phi, y - 1 - cos phi): (8.10) in both frames, the others forward only
+        const double xi = ax + sp, eta = ay - 1. - cp;
+        const double R = hy_sqrt(xi * xi + eta * eta);
+        if (R >= 2. && !angle_is_negative(xi, -eta)) // LpRmSmRm, groups 7 and 9: t = atan2(xi, -eta)
+        {
+            const double t = hy_atan2_q(xi, -eta, qa), u = 2. - R;
+            const double v = mod2pi_few_turns(t + .5 * RS_PI - aphi, beyond);
+            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+            const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hp + hy_fabs(t) : hy_fabs(t) + hp + hy_fabs(u) + hy_fabs(v);
+            offer(fam[3], t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO, (BACK ? 36 : 28) + s, L, total);
+        }
+        if (BACK)
+            return;
+        const double u1 = R * R;
+        const double SQ = hy_sqrt((u1 >= 4. || R >= 2.) ? u1 - 4. : 0.); // shared by (8.2) and (8.11)
+        // LpSpRp, group 1: t = mod2pi(atan2(eta, xi) + a) with a = atan2(2, u) in (0, pi/2]; in the third quadrant
+        // the first angle is below -pi/2 (by more than RS_DEAD when -xi > RS_DEAD * -eta), the sum negative
+        if (u1 >= 4. && !(xi < 0. && eta < 0. && -xi > RS_DEAD * -eta))
+        {
+            const double u = SQ;
+            const double t = mod2pi_few_turns(hy_atan2_q(eta, xi, qa) + hy_atan2_q(2., u, qa), beyond);
+            const double v = mod2pi_few_turns(t - aphi, beyond);
+            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+            offer(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, 4 + s, L, L);
+        }
+        {
+            const double rho = .25 * (2. + R);
+            if (rho <= 1.) // LpRupLumRm, group 4
+            {
+                const double u = hy_acos_q(rho, qa);
+                double t, v;
+                tau_omega_pm(u, false, xi, eta, aphi, t, v, beyond, qa);
+                const double L = hy_fabs(t) + 2. * hy_fabs(u) + hy_fabs(v);
+                offer(fam[2], t >= -RS_ZERO && v <= RS_ZERO, 16 + s, L, hy_fabs(t) + hy_fabs(u) + hy_fabs(u) + hy_fabs(v));
+            }
+        }
+        {
+            const double rho = (20. - xi * xi - eta * eta) / 16.;
+            if (rho >= 0 && rho <= 1) // LpRumLumRp, group 5
+            {
+                const double u = -hy_acos_q(rho, qa);
+                if (u >= -.5 * RS_PI)
+                {
+                    double t, v;
+                    tau_omega_pm(u, true, xi, eta, aphi, t, v, beyond, qa);
+                    const double L = hy_fabs(t) + 2. * hy_fabs(u) + hy_fabs(v);
+                    offer(fam[2], t >= -RS_ZERO && v >= -RS_ZERO, 20 + s, L, hy_fabs(t) + hy_fabs(u) + hy_fabs(u) + hy_fabs(v));
+                }
+            }
+        }
+        if (R >= 2.) // LpRmSLmRp, group 10
+        {
+            const double u = 4. - SQ;
+            if (u <= RS_ZERO)
+            {
+                // t = mod2pi(atan2(ty, tx)), and mod2pi leaves what atan2 returns as it is
+                const double ty = (4 - u) * xi - 2 * eta, tx = -2 * xi + (u - 4) * eta;
+                if (!angle_is_negative(ty, tx))
+                {
+                    const double t = hy_atan2_q(ty, tx, qa);
+                    const double v = mod2pi_few_turns(t - aphi, beyond);
+                    const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                    offer(fam[4], t >= -RS_ZERO && v >= -RS_ZERO, 40 + s, L, hy_fabs(t) + hp + hy_fabs(u) + hp + hy_fabs(v));
+                }
+            }
+        }
+    }
+}
+
+// rs::solve_serial(x, y, phi).total; quarter_atans: the caller's copy of HY_QUARTER_ATANS
+RS_HD double shortest_length(double x, double y, double phi, const double *quarter_atans)
+{
+    // sine is odd and cosine even bit for bit (hy_rem_pio2 and both kernels are), so -phi needs no second pass
+    double s_pos, c_pos;
+    hy_sincos(phi, &s_pos, &c_pos);
+    const double xb = x * c_pos + y * s_pos, yb = x * s_pos - y * c_pos; // the backwards frame, :205, :400
+    bool beyond = false; // some angle sum was outside what mod2pi_few_turns() reduces
+    FamilyBest fam[RS_NUM_FAMILIES];
+    for (int f = 0; f < RS_NUM_FAMILIES; ++f)
+        fam[f].l = __builtin_inf(), fam[f].total = 0., fam[f].at = RS_NUM_CANDIDATES;
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s)
+    {
+        const unsigned long long SIGN = 0x8000000000000000ull;
+        const unsigned long long flip = (s & 1) ? SIGN : 0, reflect = (s & 2) ? SIGN : 0, neg = flip ^ reflect;
+        const double aphi = flip_sign(phi, neg), sp = flip_sign(s_pos, neg);
+        offer_symmetry<false>(s, flip_sign(x, flip), flip_sign(y, reflect), aphi, sp, c_pos, fam, beyond, quarter_atans);
+        offer_symmetry<true>(s, flip_sign(xb, flip), flip_sign(yb, reflect), aphi, sp, c_pos, fam, beyond, quarter_atans);
+    }
+    if (beyond) // never with finite goals whose heading difference is a few turns at most
+        return solve_serial(x, y, phi).total;
+    double best = 1.7976931348623157e308; // empty_path().total
+    for (int f = 0; f < RS_NUM_FAMILIES; ++f)
+        if (fam[f].l < family_bound(f, best))
+            best = fam[f].total;
+    return best;
+}
+
 // Goal in the frame of q0, scaled by the turning radius (:544-550).
 RS_HD void normalise(const double q0[3], const double q1[3], double rho, double &x, double &y, double &phi)
 {

@@ -127,6 +127,34 @@ extern "C" long hg_rs_solve_uniform_mismatches(const double *xyphi, int n)
     return bad;
 }
 
+// rs::shortest_length (what the heuristic-table kernel runs: the candidates regrouped by symmetry, shared polar forms,
+// the unrolled remainder) against the total of rs::solve_serial: goals where a bit differs.  Also counts the goals
+// whose mod2pi_few_turns differs from mod2pi over a sweep of arguments derived from them.
+extern "C" long hg_rs_shortest_length_mismatches(const double *xyphi, int n)
+{
+    long bad = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const double a = rs::solve_serial(xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2]).total;
+        static const double quarter_atans[8] = HY_QUARTER_ATANS;
+        const double b = rs::shortest_length(xyphi[3 * i], xyphi[3 * i + 1], xyphi[3 * i + 2], quarter_atans);
+        bad += std::memcmp(&a, &b, 8) != 0;
+    }
+    return bad;
+}
+extern "C" long hg_mod2pi_mismatches(const double *x, int n)
+{
+    long bad = 0;
+    for (int i = 0; i < n; i++)
+    {
+        bool beyond = false;
+        const double a = rs::mod2pi(x[i]), b = rs::mod2pi_few_turns(x[i], beyond);
+        const bool outside = !(std::fabs(x[i]) < 8 * HY_PI); // then the caller takes the general form
+        bad += beyond != outside || (!beyond && std::memcmp(&a, &b, 8) != 0);
+    }
+    return bad;
+}
+
 // hy_sincos against hy_sin and hy_cos: number of arguments where a bit differs.
 extern "C" long hg_sincos_mismatches(const double *x, int n)
 {

@@ -96,6 +96,18 @@ def test_side_by_side_reeds_shepp_candidates_equal_the_plain_form(host_geom):
     # the table kernel's walk over the side-by-side candidates picks the reference walk's path
     host_geom.hg_rs_solve_uniform_mismatches.restype = C.c_long
     assert host_geom.hg_rs_solve_uniform_mismatches(g.ctypes.data_as(C.c_void_p), n) == 0
+    # the heuristic-table kernel's length-only form: candidates regrouped by symmetry, shared polar forms
+    host_geom.hg_rs_shortest_length_mismatches.restype = C.c_long
+    assert host_geom.hg_rs_shortest_length_mismatches(g.ctypes.data_as(C.c_void_p), n) == 0
+    tgrid = np.stack(np.meshgrid(np.arange(-52, 52, 0.7) / 6.0, np.arange(-52, 52, 0.9) / 6.0, np.arange(0, 73) * np.float32(2 * math.pi / 72),
+                                 indexing="ij"), -1).reshape(-1, 3)
+    tgrid = np.ascontiguousarray(tgrid, np.float64)  # a coarse copy of the table's own grid (origin and axes included)
+    assert host_geom.hg_rs_shortest_length_mismatches(tgrid.ctypes.data_as(C.c_void_p), len(tgrid)) == 0
+    T = 2 * math.pi
+    m = np.concatenate([rng.uniform(-60, 60, 400000), rng.uniform(-1e-9, 1e-9, 100), np.arange(-9, 10) * T, np.nextafter(np.arange(-9, 10) * T, 0),
+                        np.nextafter(np.arange(-9, 10) * T, 1e9), [0.0, -0.0, math.pi, -math.pi, 1e9, -1e9, 1e300, np.inf, -np.inf, np.nan]])
+    host_geom.hg_mod2pi_mismatches.restype = C.c_long
+    assert host_geom.hg_mod2pi_mismatches(np.ascontiguousarray(m).ctypes.data_as(C.c_void_p), len(m)) == 0
     host_geom.hg_rs_interp_mismatches.restype = C.c_long
     assert host_geom.hg_rs_interp_mismatches(g.ctypes.data_as(C.c_void_p), 20000, 40, C.c_double(0.35)) == 0
     x = np.concatenate([rng.uniform(-100, 100, 200000), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, math.pi / 4, -math.pi / 4, 1e5, -1e5]])
@@ -264,7 +276,8 @@ def test_adaptive_header_equals_oracle(host_geom, oracle_built):
         dsg = np.sqrt(((starts[:, 0] - goals[:, 0]) ** 2 + (starts[:, 1] - goals[:, 1]) ** 2).astype(np.float32)).astype(np.float32)
         d = np.float32(o0.utility(17, [p.steering_angle]))  # ConvertDegToRad(steering_angle)
         steer = np.array([0] + [np.float32(s) * (np.float32(i) * d) for i in range(1, (p.number_of_successors - 1) // 2 + 1) for s in (1, -1)], np.float32)
-        pairs = np.zeros((n, 13, 2), np.float32)
+        MAXP = 31  # HYAS_AD_MAX_PAIRS: forward pairs a node can have (32 successor slots, one is the reverse pair's)
+        pairs = np.zeros((n, MAXP, 2), np.float32)
         counts = np.zeros(n, np.int32)
         checked = C.c_int(0)
         host_geom.hg_step_steer_pairs(W, H, C.c_double(1.0), C.c_double(0.0), C.c_double(0.0), vp(off), vp(rr), vp(dens), C.c_float(p.obstacle_detection_range),
@@ -276,7 +289,7 @@ def test_adaptive_header_equals_oracle(host_geom, oracle_built):
         for i in range(n):
             want, nw = o.step_steer_pairs(nodes[i], goals[i], starts[i])
             want, nw = want[:nw - 1], nw - 1  # the reverse pair comes from the fixed rule
-            if nw > 13:
+            if nw > MAXP:
                 assert counts[i] == -1
                 continue
             assert counts[i] == nw, (name, mode, flags, i, counts[i], nw)
