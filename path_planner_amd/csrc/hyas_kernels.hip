@@ -596,6 +596,7 @@ __global__ void __launch_bounds__(256) k_min_distance(DevMap m, const float *__r
 // shared polar forms, candidates whose first arc is negative dropped before their arc tangents) with the arc
 // tangent's five table values in LDS; one entry per thread and many small workgroups, so that the tail of the launch
 // is one workgroup's time.
+template <typename Index> // uint32_t while the table has fewer than 2^32 entries: the index arithmetic is per entry
 __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, uint32_t nx,
                                                   const float *__restrict__ ys, uint32_t ny,
                                                   const float *__restrict__ ts, uint32_t k0, uint32_t k1, double rho,
@@ -608,17 +609,19 @@ __global__ void __launch_bounds__(256) k_table_rs(const float *__restrict__ xs, 
             s_quarter_atans[threadIdx.x] = qa[threadIdx.x];
         __syncthreads();
     }
-    const size_t total = (size_t)(k1 - k0) * ny * nx;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    const Index total = (Index)(k1 - k0) * ny * nx;
+    for (Index e = blockIdx.x * (Index)blockDim.x + threadIdx.x; e < total; e += (Index)gridDim.x * blockDim.x)
     {
         uint32_t i = (uint32_t)(e % nx);
         uint32_t j = (uint32_t)((e / nx) % ny);
-        uint32_t k = k0 + (uint32_t)(e / ((size_t)nx * ny));
+        uint32_t k = k0 + (uint32_t)(e / ((Index)nx * ny));
         const double q0[3] = {0, 0, 0};
         const double q1[3] = {(double)xs[i], (double)ys[j], (double)ts[k]};
         double x, y, phi;
         rs::normalise(q0, q1, rho, x, y, phi);
         out[e] = (float)(rho * rs::shortest_length(x, y, phi, s_quarter_atans));
+        if (sizeof(Index) == 4) // launched with one thread per entry
+            break;
     }
 }
 
@@ -2303,7 +2306,11 @@ void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny,
     if (total == 0)
         return;
     const size_t blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(k_table_rs, dim3((uint32_t)(blocks < (1u << 30) ? blocks : (1u << 30))), dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
+    const dim3 grid((uint32_t)(blocks < (1u << 30) ? blocks : (1u << 30)));
+    if (total < (1ull << 32) - 256) // one thread per entry, no index beyond 32 bits
+        hipLaunchKernelGGL(k_table_rs<uint32_t>, grid, dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
+    else
+        hipLaunchKernelGGL(k_table_rs<size_t>, grid, dim3(256), 0, s, xs, nx, ys, ny, ts, k0, k1, rho, out);
 }
 
 void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,

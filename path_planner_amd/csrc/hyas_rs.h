@@ -652,8 +652,25 @@ RS_HD void offer(FamilyBest &b, bool ok, int c, double L, double total)
     b.total = take ? total : b.total;
     b.at = take ? c : b.at;
 }
+// Where equal L means equal totals (CSC: the total is L itself) or the candidates arrive in reference order
+// (CCSCC: one group, its symmetries in order), which of two equals is kept makes no difference.
+RS_HD void offer_any_of_equals(FamilyBest &b, bool ok, double L, double total)
+{
+    const bool take = ok && L < b.l;
+    b.l = take ? L : b.l;
+    b.total = take ? total : b.total;
+}
 // atan2(y, x) is certainly below -RS_ZERO
 RS_HD bool angle_is_negative(double y, double x) { return y < 0. && !(-y <= RS_DEAD * x); }
+// mod2pi(atan2(ay, ax) + atan2(by, bx)) is certainly below -RS_ZERO: the sum is the angle of the product of
+// (ax + i ay) and (bx + i by), whose imaginary part is ax by + ay bx.  Where that is negative by more than 1e-13 of
+// (|ax| + |ay|)(|bx| + |by|) -- a bound of the product's modulus and, times 1e-15, of the rounding in it -- the true
+// angle lies inside (-pi + 1e-13, -1e-13), and the computed one, a few 1e-16 away, is folded to the same side.
+RS_HD bool angle_sum_is_negative(double ay, double ax, double by, double bx)
+{
+    const double im = ax * by + ay * bx, m = (hy_fabs(ax) + hy_fabs(ay)) * (hy_fabs(bx) + hy_fabs(by));
+    return -im > 1e-13 * m;
+}
 
 // The candidates of symmetry s in one frame, (X, Y) being the goal there with the symmetry's signs applied.
 template <bool BACK>
@@ -663,41 +680,48 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
     {
         // forms on (x - sin phi, y - 1 + cos phi): (8.1) forward only, (8.3/8.4) and (8.9) in both frames
         const double xi = ax - sp, eta = ay - 1. + cp;
-        const double R = hy_sqrt(xi * xi + eta * eta), TH = hy_atan2_q(eta, xi, qa);
-        if (!BACK) // LpSpLp, group 0
+        const double R = hy_sqrt(xi * xi + eta * eta);
+        // (8.9): t = mod2pi(atan2(eta, xi) + atan2(r, -2))
+        const double r = hy_sqrt(R >= 2. ? R * R - 4. : 0.);
+        const bool first = !BACK && !angle_is_negative(eta, xi), second = R <= 4., third = R >= 2. && !angle_sum_is_negative(eta, xi, r, -2.);
+        if (first || second || third)
         {
-            const double t = TH, u = R;
-            const double v = mod2pi_few_turns(aphi - t, beyond);
-            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-            offer(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, 0 + s, L, L);
-        }
-        if (R <= 4.) // LpRmL, groups 2 and 3
-        {
-            const double u = -2. * hy_asin_q(.25 * R, qa);
-            const double t = mod2pi_few_turns(TH + .5 * u + RS_PI, beyond);
-            const double v = mod2pi_few_turns(aphi - t + u, beyond);
-            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-            const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hy_fabs(t) : L;
-            offer(fam[1], t >= -RS_ZERO && u <= RS_ZERO, (BACK ? 12 : 8) + s, L, total);
-        }
-        // LpRmSmLm, groups 6 and 8: t = mod2pi(TH + a) with a = atan2(r, -2) in [pi/2, pi]; for TH inside
-        // (pi/2, pi) the sum lies inside (pi, 2 pi) and t inside (-pi, 0)
-        if (R >= 2. && !(TH > hp + RS_DEAD && TH < RS_PI - RS_DEAD))
-        {
-            const double r = hy_sqrt(R * R - 4.);
-            const double u = 2. - r;
-            const double t = mod2pi_few_turns(TH + hy_atan2_q(r, -2., qa), beyond);
-            const double v = mod2pi_few_turns(aphi - .5 * RS_PI - t, beyond);
-            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-            const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hp + hy_fabs(t) : hy_fabs(t) + hp + hy_fabs(u) + hy_fabs(v);
-            offer(fam[3], t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO, (BACK ? 32 : 24) + s, L, total);
+            const double TH = hy_atan2_q(eta, xi, qa);
+            if (first) // LpSpLp, group 0
+            {
+                const double t = TH, u = R;
+                const double v = mod2pi_few_turns(aphi - t, beyond);
+                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                offer_any_of_equals(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, L, L);
+            }
+            if (second) // LpRmL, groups 2 and 3
+            {
+                const double u = -2. * hy_asin_q(.25 * R, qa);
+                const double t = mod2pi_few_turns(TH + .5 * u + RS_PI, beyond);
+                const double v = mod2pi_few_turns(aphi - t + u, beyond);
+                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hy_fabs(t) : L;
+                offer(fam[1], t >= -RS_ZERO && u <= RS_ZERO, (BACK ? 12 : 8) + s, L, total);
+            }
+            if (third) // LpRmSmLm, groups 6 and 8
+            {
+                const double u = 2. - r;
+                const double t = mod2pi_few_turns(TH + hy_atan2_q(r, -2., qa), beyond);
+                const double v = mod2pi_few_turns(aphi - .5 * RS_PI - t, beyond);
+                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hp + hy_fabs(t) : hy_fabs(t) + hp + hy_fabs(u) + hy_fabs(v);
+                offer(fam[3], t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO, (BACK ? 32 : 24) + s, L, total);
+            }
         }
     }
     {
         // forms on (x + sin phi, y - 1 - cos phi): (8.10) in both frames, the others forward only
         const double xi = ax + sp, eta = ay - 1. - cp;
+        const bool fourth = !angle_is_negative(xi, -eta); // (8.10): t = atan2(xi, -eta)
+        if (BACK && !fourth)
+            return;
         const double R = hy_sqrt(xi * xi + eta * eta);
-        if (R >= 2. && !angle_is_negative(xi, -eta)) // LpRmSmRm, groups 7 and 9: t = atan2(xi, -eta)
+        if (R >= 2. && fourth) // LpRmSmRm, groups 7 and 9
         {
             const double t = hy_atan2_q(xi, -eta, qa), u = 2. - R;
             const double v = mod2pi_few_turns(t + .5 * RS_PI - aphi, beyond);
@@ -709,15 +733,14 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
             return;
         const double u1 = R * R;
         const double SQ = hy_sqrt((u1 >= 4. || R >= 2.) ? u1 - 4. : 0.); // shared by (8.2) and (8.11)
-        // LpSpRp, group 1: t = mod2pi(atan2(eta, xi) + a) with a = atan2(2, u) in (0, pi/2]; in the third quadrant
-        // the first angle is below -pi/2 (by more than RS_DEAD when -xi > RS_DEAD * -eta), the sum negative
-        if (u1 >= 4. && !(xi < 0. && eta < 0. && -xi > RS_DEAD * -eta))
+        // LpSpRp, group 1: t = mod2pi(atan2(eta, xi) + atan2(2, u))
+        if (u1 >= 4. && !angle_sum_is_negative(eta, xi, 2., SQ))
         {
             const double u = SQ;
             const double t = mod2pi_few_turns(hy_atan2_q(eta, xi, qa) + hy_atan2_q(2., u, qa), beyond);
             const double v = mod2pi_few_turns(t - aphi, beyond);
             const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-            offer(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, 4 + s, L, L);
+            offer_any_of_equals(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, L, L);
         }
         {
             const double rho = .25 * (2. + R);
@@ -756,7 +779,7 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
                     const double t = hy_atan2_q(ty, tx, qa);
                     const double v = mod2pi_few_turns(t - aphi, beyond);
                     const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-                    offer(fam[4], t >= -RS_ZERO && v >= -RS_ZERO, 40 + s, L, hy_fabs(t) + hp + hy_fabs(u) + hp + hy_fabs(v));
+                    offer_any_of_equals(fam[4], t >= -RS_ZERO && v >= -RS_ZERO, L, hy_fabs(t) + hp + hy_fabs(u) + hp + hy_fabs(v));
                 }
             }
         }
