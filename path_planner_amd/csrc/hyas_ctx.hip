@@ -1099,10 +1099,34 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
             step(hipMalloc((void **)&c->d_cell_off, (cells + 1) * sizeof(uint32_t) + slack), "hipMalloc(list offsets)");
         if (rc == HYAS_OK)
             step(hipMemsetAsync((char *)c->d_cell_off + (cells + 1) * sizeof(uint32_t), 0, slack, c->stream), "list offsets");
+        // bins of polygons per tile of grid keys first (lengths, prefix sum, ids), then the keys' lists out of them
+        RangeBins bins{};
+        bins.tiles_x = ((uint32_t)w + HYAS_BIN_TILE - 1) / HYAS_BIN_TILE, bins.tiles_y = ((uint32_t)h + HYAS_BIN_TILE - 1) / HYAS_BIN_TILE;
+        bins.extra = std::getenv("HYAS_ALL_POLYGONS_IN_BINS") ? INFINITY : 0.f; // test aid: every key is tested against every polygon
+        const size_t tiles = (size_t)bins.tiles_x * bins.tiles_y;
+        unsigned long long bin_total = 0;
+        if (rc == HYAS_OK)
+            step(hipMalloc((void **)&bins.off, (tiles + 1) * sizeof(uint32_t)), "hipMalloc(bin offsets)");
         if (rc == HYAS_OK)
         {
-            launch_in_range_lists(m, c->d_quads, (uint32_t)nq, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range,
-                                  d_owner, c->d_cell_off, nullptr, d_total, 0, c->stream);
+            launch_range_bins(m, c->d_quads, (uint32_t)nq, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range, d_owner, bins,
+                              d_total, 0, c->stream);
+            step(hipGetLastError(), "polygon bin lengths");
+        }
+        if (rc == HYAS_OK)
+            step(hipMemcpyAsync(&bin_total, d_total, sizeof(bin_total), hipMemcpyDeviceToHost, c->stream), "polygon bin lengths");
+        if (rc == HYAS_OK)
+            step(hipStreamSynchronize(c->stream), "polygon bin lengths");
+        if (rc == HYAS_OK && bin_total >= (1ull << 32))
+            rc = c->fail(HYAS_ERANGE, "the polygon bins hold 2^32 entries or more");
+        if (rc == HYAS_OK)
+            step(hipMalloc((void **)&bins.idx, ((size_t)bin_total + 1) * sizeof(uint16_t)), "hipMalloc(bin entries)");
+        if (rc == HYAS_OK)
+        {
+            launch_range_bins(m, c->d_quads, (uint32_t)nq, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range, d_owner, bins,
+                              d_total, 1, c->stream);
+            launch_in_range_lists(m, c->d_quads, d_xs, d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range, d_owner, bins, c->d_cell_off, nullptr, d_total,
+                                  0, c->stream);
             step(hipGetLastError(), "in-range list lengths");
         }
         if (rc == HYAS_OK)
@@ -1117,8 +1141,8 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
             step(hipMemsetAsync((char *)c->d_cell_idx + (size_t)total * sizeof(uint16_t), 0, slack, c->stream), "list entries");
         if (rc == HYAS_OK)
         {
-            launch_in_range_lists(m, c->d_quads, (uint32_t)nq, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range,
-                                  d_owner, c->d_cell_off, c->d_cell_idx, d_total, 1, c->stream);
+            launch_in_range_lists(m, c->d_quads, d_xs, d_ys, (uint32_t)ys.size(), c->P.obstacle_detection_range, d_owner, bins, c->d_cell_off, c->d_cell_idx,
+                                  d_total, 1, c->stream);
             step(hipGetLastError(), "in-range lists");
         }
         // the host keeps copies: list pruning, the adaptive maps and the getters read them
@@ -1131,7 +1155,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
             step(hipMemcpyAsync(owner_u.data(), d_owner, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "in-range lists");
         if (rc == HYAS_OK)
             step(hipStreamSynchronize(c->stream), "in-range lists");
-        for (void *p : {(void *)d_xs, (void *)d_ys, (void *)d_owner, (void *)d_total})
+        for (void *p : {(void *)d_xs, (void *)d_ys, (void *)d_owner, (void *)d_total, (void *)bins.off, (void *)bins.idx})
             if (p)
                 (void)hipFree(p);
         if (rc != HYAS_OK)

@@ -60,9 +60,22 @@ void launch_collision(const DevMap &m, int mode, const float *xyt, const float *
 // map ingest: occupancy values, occupancy bit tiles (padded may be null), per-key in-range lists.
 void launch_occupancy(const uint8_t *cost, size_t n, int8_t *occ, hipStream_t s);
 void launch_occ_tiles(const uint8_t *cost, uint32_t w, uint32_t h, uint32_t tx, uint32_t ty, uint64_t *tiles, uint64_t *padded, hipStream_t s);
-// pass 0: owner[key] (w*h entries), off[0..w*h] = offsets of the lists, *total = their sum; pass 1: idx filled (total entries).
-void launch_in_range_lists(const DevMap &m, const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
-                           uint32_t *owner, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s);
+// In-range lists in two steps of two passes each, so that nothing is tested against every polygon: bins of polygons
+// per tile of HYAS_BIN_TILE x HYAS_BIN_TILE grid keys, then each key's list from the bin of its tile.
+#define HYAS_BIN_TILE 16u
+struct RangeBins
+{
+    uint32_t tiles_x, tiles_y;
+    float extra;   // added to the growth of the boxes: 0, or infinity to put every polygon into every bin
+    uint32_t *off; // tiles_x * tiles_y + 1 entries
+    uint16_t *idx; // polygon ids, tile after tile, ascending inside a tile
+};
+// pass 0: owner[key] (w*h entries), bins.off = offsets of the bins, *total = their sum; pass 1: bins.idx filled.
+void launch_range_bins(const DevMap &m, const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
+                       uint32_t *owner, RangeBins bins, unsigned long long *total, int pass, hipStream_t s);
+// pass 0: off[0..w*h] = offsets of the lists, *total = their sum; pass 1: idx filled (total entries).
+void launch_in_range_lists(const DevMap &m, const Quad *quads, const float *xs, const float *ys, uint32_t nys, float range, const uint32_t *owner,
+                           RangeBins bins, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s);
 void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,
                            float *out, hipStream_t s);
 void launch_min_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float *out, hipStream_t s);

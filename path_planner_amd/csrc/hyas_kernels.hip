@@ -454,13 +454,72 @@ __global__ void __launch_bounds__(256) k_cell_owner(DevMap m, const float *__res
     }
 }
 
-// The in-range list of every grid key (src/collisiondetection.cpp:335-345): the obstacle polygons nearer than `range`
-// to the key's owner corner, in obstacle order.  One wave per key, 64 polygons per pass, positions inside a pass by
-// ballot.  FILL = false counts (off[key] = list length), FILL = true writes the ids behind off[key].
+// Bins for the in-range lists: the grid keys in tiles of HYAS_BIN_TILE x HYAS_BIN_TILE, and per tile the obstacle
+// polygons whose bounding box, grown by `range`, reaches the box around the owner corners of the tile's keys, in
+// obstacle order.  A polygon nearer than `range` to a corner has its bounding box nearer still, so a key's list is a
+// sub-sequence of its tile's bin; the growth is a little more than `range`, to cover the rounding of the distance.
+// One wave per tile, 64 polygons per pass, positions inside a pass by ballot.  FILL = false counts
+// (off[tile] = bin length), FILL = true writes the ids behind off[tile].
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_in_range_lists(const Quad *__restrict__ quads, uint32_t n_quads, const float *__restrict__ xs,
-                                                        const float *__restrict__ ys, uint32_t nys, const uint32_t *__restrict__ owner, uint32_t cells,
-                                                        float range, uint32_t *__restrict__ off, uint16_t *__restrict__ idx)
+__global__ void __launch_bounds__(256) k_range_bins(const Quad *__restrict__ quads, uint32_t n_quads, const float *__restrict__ xs,
+                                                    const float *__restrict__ ys, uint32_t nys, const uint32_t *__restrict__ owner, uint32_t w, uint32_t h,
+                                                    float range, RangeBins bins)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles = bins.tiles_x * bins.tiles_y;
+    const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    for (size_t t = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6); t < tiles; t += waves)
+    {
+        const uint32_t x0 = (uint32_t)(t % bins.tiles_x) * HYAS_BIN_TILE, y0 = (uint32_t)(t / bins.tiles_x) * HYAS_BIN_TILE;
+        float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+        for (uint32_t k = lane; k < HYAS_BIN_TILE * HYAS_BIN_TILE; k += 64)
+        {
+            const uint32_t kx = x0 + k % HYAS_BIN_TILE, ky = y0 + k / HYAS_BIN_TILE;
+            const uint32_t pos = kx < w && ky < h ? owner[(size_t)ky * w + kx] : 0xFFFFFFFFu;
+            if (pos != 0xFFFFFFFFu)
+            {
+                const float px = xs[pos / nys], py = ys[pos % nys];
+                xlo = fminf(xlo, px), xhi = fmaxf(xhi, px), ylo = fminf(ylo, py), yhi = fmaxf(yhi, py);
+            }
+        }
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            xlo = fminf(xlo, __shfl_xor(xlo, d, 64)), xhi = fmaxf(xhi, __shfl_xor(xhi, d, 64));
+            ylo = fminf(ylo, __shfl_xor(ylo, d, 64)), yhi = fmaxf(yhi, __shfl_xor(yhi, d, 64));
+        }
+        uint32_t n = 0;
+        if (xlo <= xhi)
+        {
+            const float grow = range + 1e-3f * range + 1e-5f * (fabsf(xlo) + fabsf(xhi) + fabsf(ylo) + fabsf(yhi) + 1.f) + bins.extra;
+            const uint32_t base = FILL ? bins.off[t] : 0u;
+            for (uint32_t q0 = 0; q0 < n_quads; q0 += 64)
+            {
+                const uint32_t q = q0 + lane;
+                bool hit = false;
+                if (q < n_quads)
+                {
+                    const float4 box = *reinterpret_cast<const float4 *>(&quads[q].xmin); // xmin, ymin, xmax, ymax
+                    hit = box.x - grow <= xhi && box.z + grow >= xlo && box.y - grow <= yhi && box.w + grow >= ylo;
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (FILL && hit)
+                    bins.idx[base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)q;
+                n += (uint32_t)__popcll(mask);
+            }
+        }
+        if (!FILL && lane == 0)
+            bins.off[t] = n;
+    }
+}
+
+// The in-range list of every grid key (src/collisiondetection.cpp:335-345): the obstacle polygons nearer than `range`
+// to the key's owner corner, in obstacle order, picked from the bin of the key's tile.  One wave per key, 64 polygons
+// per pass, positions inside a pass by ballot.  FILL = false counts (off[key] = list length), FILL = true writes the
+// ids behind off[key].
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_in_range_lists(const Quad *__restrict__ quads, const float *__restrict__ xs, const float *__restrict__ ys,
+                                                        uint32_t nys, const uint32_t *__restrict__ owner, uint32_t w, uint32_t cells, float range,
+                                                        RangeBins bins, uint32_t *__restrict__ off, uint16_t *__restrict__ idx)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
@@ -472,10 +531,13 @@ __global__ void __launch_bounds__(256) k_in_range_lists(const Quad *__restrict__
         {
             const F2 p = f2(xs[pos / nys], ys[pos % nys]);
             const uint32_t base = FILL ? off[key] : 0u;
-            for (uint32_t q0 = 0; q0 < n_quads; q0 += 64)
+            const uint32_t t = (uint32_t)(key / w) / HYAS_BIN_TILE * bins.tiles_x + (uint32_t)(key % w) / HYAS_BIN_TILE;
+            const uint32_t b1 = bins.off[t + 1];
+            for (uint32_t b0 = bins.off[t]; b0 < b1; b0 += 64)
             {
-                const uint32_t q = q0 + lane;
-                const bool hit = q < n_quads && dist_quad_point(quads[q], p) < range;
+                const bool have = b0 + lane < b1;
+                const uint32_t q = have ? bins.idx[b0 + lane] : 0u;
+                const bool hit = have && dist_quad_point(quads[q], p) < range;
                 const unsigned long long mask = __ballot(hit);
                 if (FILL && hit)
                     idx[base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)q;
@@ -2265,8 +2327,27 @@ void launch_occ_tiles(const uint8_t *cost, uint32_t w, uint32_t h, uint32_t tx, 
     hipLaunchKernelGGL(k_occ_tiles, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, cost, w, h, tx, ty, tiles, padded);
 }
 
-void launch_in_range_lists(const DevMap &m, const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
-                           uint32_t *owner, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s)
+void launch_range_bins(const DevMap &m, const Quad *quads, uint32_t n_quads, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float range,
+                       uint32_t *owner, RangeBins bins, unsigned long long *total, int pass, hipStream_t s)
+{
+    const uint32_t cells = m.w * m.h, tiles = bins.tiles_x * bins.tiles_y;
+    if (cells == 0)
+        return;
+    const int grid = grid_for(tiles, 4, 256 * 32); // four waves (tiles) per workgroup
+    if (pass == 0)
+    {
+        hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(cells)), dim3(256), 0, s, owner, (size_t)cells, 0xFFFFFFFFu);
+        if ((size_t)nxs * nys)
+            hipLaunchKernelGGL(k_cell_owner, dim3(grid_for((size_t)nxs * nys)), dim3(256), 0, s, m, xs, nxs, ys, nys, owner);
+        hipLaunchKernelGGL(k_range_bins<false>, dim3(grid), dim3(256), 0, s, quads, n_quads, xs, ys, nys, owner, m.w, m.h, range, bins);
+        hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, bins.off, (size_t)tiles, total);
+    }
+    else
+        hipLaunchKernelGGL(k_range_bins<true>, dim3(grid), dim3(256), 0, s, quads, n_quads, xs, ys, nys, owner, m.w, m.h, range, bins);
+}
+
+void launch_in_range_lists(const DevMap &m, const Quad *quads, const float *xs, const float *ys, uint32_t nys, float range, const uint32_t *owner,
+                           RangeBins bins, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s)
 {
     const uint32_t cells = m.w * m.h;
     if (cells == 0)
@@ -2274,14 +2355,11 @@ void launch_in_range_lists(const DevMap &m, const Quad *quads, uint32_t n_quads,
     const int grid = grid_for(cells, 4, 256 * 32); // four waves (keys) per workgroup
     if (pass == 0)
     {
-        hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(cells)), dim3(256), 0, s, owner, (size_t)cells, 0xFFFFFFFFu);
-        if ((size_t)nxs * nys)
-            hipLaunchKernelGGL(k_cell_owner, dim3(grid_for((size_t)nxs * nys)), dim3(256), 0, s, m, xs, nxs, ys, nys, owner);
-        hipLaunchKernelGGL(k_in_range_lists<false>, dim3(grid), dim3(256), 0, s, quads, n_quads, xs, ys, nys, owner, cells, range, off, idx);
+        hipLaunchKernelGGL(k_in_range_lists<false>, dim3(grid), dim3(256), 0, s, quads, xs, ys, nys, owner, m.w, cells, range, bins, off, idx);
         hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, off, (size_t)cells, total);
     }
     else
-        hipLaunchKernelGGL(k_in_range_lists<true>, dim3(grid), dim3(256), 0, s, quads, n_quads, xs, ys, nys, owner, cells, range, off, idx);
+        hipLaunchKernelGGL(k_in_range_lists<true>, dim3(grid), dim3(256), 0, s, quads, xs, ys, nys, owner, m.w, cells, range, bins, off, idx);
 }
 
 void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,

@@ -102,6 +102,32 @@ def test_in_range_list_contents(parking, maze):
     assert np.array_equal(o.collision(xyt), h.collision(xyt))
 
 
+def test_in_range_lists_from_tile_bins_on_a_large_map(monkeypatch):
+    """The lists are picked from bins of polygons per 16 x 16 tile of keys instead of testing every polygon against every
+    key.  On a random 800 x 600 costmap (about 14 000 polygons, where the oracle's own assembly would take minutes) they
+    must equal the lists of a build whose bins hold every polygon, which is the exhaustive assembly the other list tests
+    check against the oracle: every key's length, every fifth key's polygons in order, and the verdicts of poses."""
+    rng = np.random.default_rng(2)
+    m = np.zeros((600, 800), np.uint8)
+    m[rng.random((600, 800)) < 0.03] = 254
+    _, ph = _params(position_resolution=1)
+    binned = Hyas(ph)
+    binned.set_costmap(m, build_table=False)
+    monkeypatch.setenv("HYAS_ALL_POLYGONS_IN_BINS", "1")
+    exhaustive = Hyas(ph)
+    exhaustive.set_costmap(m, build_table=False)
+    monkeypatch.delenv("HYAS_ALL_POLYGONS_IN_BINS")
+    assert binned.obstacles().shape[0] > 10000
+    a = np.array([binned.in_range_count(k) for k in range(m.size)])
+    b = np.array([exhaustive.in_range_count(k) for k in range(m.size)])
+    assert np.array_equal(a, b) and a.max() > 8
+    for key in range(0, m.size, 5):
+        la, lb = binned.in_range_list(key), exhaustive.in_range_list(key)
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), key
+    xyt = np.stack([rng.uniform(1, 799, 200000), rng.uniform(1, 599, 200000), rng.uniform(0, 6.28, 200000)], 1).astype(np.float32)
+    assert np.array_equal(binned.collision(xyt), exhaustive.collision(xyt))
+
+
 def test_map_boundary_obstacle(oracle_built):
     """map_boundary_obstacle = 1 (CollisionDetection::AddMapBoundaryAsObstacle, src/collisiondetection.cpp:1223-1240):
     four rectangles around the grid, in cells whatever resolution and origin are, join the obstacle polygons behind the
