@@ -226,6 +226,36 @@ def rs_table(args):
     }
 
 
+def _round_kernel_roofline(ctx, calls, what):
+    """The search-round kernel's roofline object for a workload given as a list of (starts, goals) calls, measured in
+    two untimed passes over them: one with HIP events round the launches (duration), one with the work counters on
+    (algorithmic bytes, as bench.py counts them)."""
+    from bench import HBM_PEAK_GBS, algorithmic_bytes
+
+    ctx.set_round_timing(1)
+    kms = kl = 0
+    for s_, g_ in calls:
+        ctx.plan_batch(s_, g_)
+        a, b = ctx.kernel_ms(0)
+        kms, kl = kms + a, kl + b
+    ctx.set_round_timing(0)
+    ctx.set_stats(1)
+    launches = 0
+    for s_, g_ in calls:
+        ctx.plan_batch(s_, g_)
+        launches += ctx.kernel_ms(0)[1]
+    st = ctx.stats()
+    ctx.set_stats(0)
+    avg_ms = kms / max(kl, 1)
+    per_launch = algorithmic_bytes(st) / max(launches, 1)
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_round", "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": per_launch, "launches": launches,
+            "measured_on": what,
+            "note": "HIP events on the launching streams, in passes of their own; bytes are those of the reference's serial scan "
+                    "(bench.py algorithmic_bytes), every node a launch processed counted; no counter pass for this workload"}
+
+
 def queries_large(args):
     torch, dist, rank, local_rank, world = _dist_setup()
     from path_planner_amd import Hyas, hot_path_params
@@ -258,6 +288,13 @@ def queries_large(args):
     if rank != 0:
         return None
     status = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
+    sub = min(len(starts), 2048)
+    roofline = _round_kernel_roofline(ctx, [(starts[:sub], goals[:sub])], f"the first {sub} queries of rank 0's block, one call")
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from bench import cpu_baseline
+
+        cpu = cpu_baseline(mp, starts, goals, budget_s=12.0)
     return {
         "metric": "collision-checked node expansions/sec", "value": succ / total_s, "unit": "successors/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
@@ -265,8 +302,8 @@ def queries_large(args):
         "config": {"workload": f"map_large 180x60, {total_q} queries " + ("in contiguous blocks over" if scaling == "strong" else "on each of")
                                + f" {world} GPU(s), Reeds-Shepp shot every pop"},
         "queries_per_s": nq / total_s, "nodes_expanded_per_s": expd / total_s, "status_counts_rank0": status,
-        "round_kernel_avg_us_rank0": 1e3 * kms / max(kl, 1),
-        "roofline": None, "cpu_baseline": None,
+        "round_kernel_avg_us_rank0": roofline["avg_launch_us"],
+        "roofline": roofline, "cpu_baseline": cpu,
     }
 
 
@@ -302,6 +339,12 @@ def single_query(args):
     if rank != 0:
         return None
     lat = np.array(lat) * 1e3
+    roofline = _round_kernel_roofline(ctx, [(starts[i:i + 1], goals[i:i + 1]) for i in range(nq)], f"rank 0's {nq} queries, one call each")
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from bench import cpu_baseline
+
+        cpu = cpu_baseline(mp, starts, goals, budget_s=12.0)
     return {
         "metric": "collision-checked node expansions/sec", "value": succ / total_s, "unit": "successors/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s / args.steps, "higher_is_better": True,
@@ -310,7 +353,7 @@ def single_query(args):
         "queries_per_s": n_done / total_s, "nodes_expanded_per_s": expd / total_s,
         "latency_ms_rank0": {"mean": float(lat.mean()), "median": float(np.median(lat)), "p90": float(np.percentile(lat, 90)), "max": float(lat.max())},
         "rounds_per_query": launches / n_done, "expansions_per_round": expd / max(launches, 1.0),
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": cpu,
     }
 
 
@@ -356,7 +399,10 @@ def modes(args):
         for _ in range(args.steps):
             res = ctx.plan_batch(starts, goals)
         sec = (time.perf_counter() - t0) / args.steps
+        ctx.set_round_timing(1)  # the timed calls carry no timing events: one more pass for the kernel's duration
+        ctx.plan_batch(starts, goals)
         kms, kl = ctx.kernel_ms(0)
+        ctx.set_round_timing(0)
         status = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
         row = {"map_setup_ms": setup_ms, "ms_per_batch": sec * 1e3, "queries_per_s": nq / sec,
                "successors_per_s": float(res["successors"].sum()) / sec, "nodes_expanded_per_s": float(res["nodes_expanded"].sum()) / sec,

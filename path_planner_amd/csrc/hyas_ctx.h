@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,7 @@ struct hyas_ctx
     hipStream_t round_stream[HYAS_MAX_GROUPS] = {};
     hipEvent_t round_ev[HYAS_MAX_GROUPS][2] = {};
     std::string err;
+    std::mutex err_mutex; // a batch's set-up thread and its main thread may both report
     bool have_map = false, have_table = false, grid_only = false;
 
     // host-side map state
@@ -105,6 +107,7 @@ struct hyas_ctx
 
     int fail(int code, const std::string &msg)
     {
+        std::lock_guard<std::mutex> lock(err_mutex);
         err = msg;
         return code;
     }

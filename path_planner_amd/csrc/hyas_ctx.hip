@@ -31,7 +31,10 @@ int hip_fail(hyas_ctx *c, hipError_t e, const char *what)
     char buf[512];
     snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
     if (c)
+    {
+        std::lock_guard<std::mutex> lock(c->err_mutex);
         c->err = buf;
+    }
     return (e == hipErrorOutOfMemory) ? HYAS_ENOMEM : HYAS_ENODEV;
 }
 
