@@ -30,15 +30,18 @@ struct Ent
 };
 
 // std::__push_heap(first, hole, top, value, comp) with comp(a, b) = a.prio >= b.prio
+// (every entry is fetched once and kept: a fetch is a trip to memory whose answer the next step has to wait for)
 template <class Heap>
 HD void sift_up(Heap &h, int hole, int top, const Ent &value)
 {
-    int parent = (hole - 1) / 2;
-    while (hole > top && h.get(parent).prio >= value.prio)
+    while (hole > top)
     {
-        h.set(hole, h.get(parent));
+        const int parent = (hole - 1) / 2;
+        const Ent pe = h.get(parent);
+        if (!(pe.prio >= value.prio))
+            break;
+        h.set(hole, pe);
         hole = parent;
-        parent = (hole - 1) / 2;
     }
     h.set(hole, value);
 }
@@ -63,9 +66,11 @@ HD Ent pop(Heap &h, int size)
     while (child < (len - 1) / 2)
     {
         child = 2 * (child + 1);
-        if (h.get(child).prio >= h.get(child - 1).prio)
+        const Ent right = h.get(child), left = h.get(child - 1); // both children in one trip
+        const bool take_left = right.prio >= left.prio;
+        if (take_left)
             child--;
-        h.set(hole, h.get(child));
+        h.set(hole, take_left ? left : right);
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2)

@@ -23,3 +23,7 @@ timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 10 > gpurun
 echo "extras done"
 HYAS_TRACE=1 timeout -k 10 600 python3 -u bench.py --workload queries_large --steps 1 --warmup 0 > gpurun_out/meas/extra_queries_large.json 2> gpurun_out/meas/extra_queries_large.log
 echo "large done"
+timeout -k 10 300 python3 -u bench.py --workload single_query > gpurun_out/meas/extra_single_query.json
+timeout -k 10 400 python3 -u bench.py --workload modes > gpurun_out/meas/extra_modes.json
+timeout -k 10 300 python3 -u bench.py --workload footprint_checks_car > gpurun_out/meas/extra_footprint_car.json
+echo "single, modes, car done"

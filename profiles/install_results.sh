@@ -17,6 +17,7 @@ if line.get("roofline"):
 open(f"profiles/{r}_bench_line.json", "w").write(json.dumps(line) + "\n")
 print(json.dumps(line)[:600])
 PY
-for x in footprint table_pr1 table_pr10 queries_large; do
-    [ -s gpurun_out/meas/extra_$x.json ] && tail -n 1 gpurun_out/meas/extra_$x.json > profiles/${r}_extra_$x.json
+for x in footprint footprint_car table_pr1 table_pr10 queries_large single_query modes; do
+    if [ -s gpurun_out/meas/extra_$x.json ]; then tail -n 1 gpurun_out/meas/extra_$x.json > profiles/${r}_extra_$x.json; fi
 done
+if [ -s gpurun_out/meas/extra_queries_large.log ]; then grep "^hyas chunk\|^hyas rounds (" gpurun_out/meas/extra_queries_large.log > profiles/${r}_extra_queries_large_trace.txt; fi
