@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fcntl.h>
 #include <unistd.h>
@@ -1045,6 +1046,16 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     m.delta_heading = (float)(2 * HY_PI / (double)(float)c->P.headings); // src/lookup_table.cpp:127
     fill_motion_set(c);
 
+    // HYAS_TRACE: where the time of the ingest goes
+    const bool trace_ingest = std::getenv("HYAS_TRACE") != nullptr;
+    auto t_mark = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace_ingest)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "hyas ingest: %-44s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+    };
     // obstacles + per-key lists
     std::vector<float> xs, ys;
     cell_axes(c, xs, ys);
@@ -1067,7 +1078,9 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
         if (e != hipSuccess)
             return hip_fail(c, e, "occupancy values");
     }
+    mark("cost bytes up, occupancy values back");
     extract_obstacles(c, occ, xs, ys);
+    mark("rectangle scan (host)");
     if (c->quads.size() > 32767)
         return c->fail(HYAS_ERANGE, "more than 32767 obstacle polygons");
     if ((rc = upload(c, c->d_quads, c->quads)) != HYAS_OK)
@@ -1166,27 +1179,82 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
         for (size_t key = 0; key < cells; ++key)
             owner[key] = owner_u[key] == 0xFFFFFFFFu ? -1 : (int64_t)owner_u[key];
     }
+    mark("polygon bins and in-range lists, copies back");
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
     m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx;
     if (m.ad_mode != 0 && (rc = build_adaptive_maps(c, xs, ys, owner)) != HYAS_OK)
         return rc;
+    mark("adaptive maps");
     {
         // successor steps are 0.2 m, curve samples 0.1 x resolution apart
         const float lmax = std::max(0.3f, 0.2f * (float)res);
-        std::vector<uint32_t> pose_off, seg_off;
-        std::vector<uint16_t> pose_idx, seg_idx;
-        prune_lists(m, c->quads.data(), c->cell_off.data(), c->cell_idx.data(), lmax, pose_off, pose_idx, seg_off, seg_idx);
-        if ((rc = upload(c, c->d_pose_off, pose_off)) != HYAS_OK || (rc = upload(c, c->d_pose_idx, pose_idx)) != HYAS_OK ||
-            (rc = upload(c, c->d_seg_off, seg_off)) != HYAS_OK || (rc = upload(c, c->d_seg_idx, seg_idx)) != HYAS_OK)
-            return rc;
+        // pruned lists on the GPU, straight from the full lists in HBM: lengths, prefix sums, ids; neither list can be
+        // longer than the full one, so the ids are allocated before their number is known
+        const size_t slack = 64, full = c->cell_idx.size();
+        const PruneMargins pm = prune_margins(m, lmax);
+        PruneArgs pa{};
+        pa.res = m.res, pa.ox = m.ox, pa.oy = m.oy, pa.diag = pm.diag, pa.reach = pm.reach, pa.lmax = (double)lmax, pa.slack = pm.slack;
+        pa.w = m.w, pa.cells = (uint32_t)cells;
+        unsigned long long *d_totals = nullptr, totals[2] = {0, 0};
+        HYAS_HIP(c, hipMalloc((void **)&d_totals, 2 * sizeof(unsigned long long)));
+        hipError_t e = hipMalloc((void **)&c->d_pose_off, (cells + 1) * sizeof(uint32_t) + slack);
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&c->d_seg_off, (cells + 1) * sizeof(uint32_t) + slack);
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&c->d_pose_idx, std::max<size_t>(full, 1) * sizeof(uint16_t) + slack);
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&c->d_seg_idx, std::max<size_t>(full, 1) * sizeof(uint16_t) + slack);
+        if (e == hipSuccess)
+            e = hipMemsetAsync((char *)c->d_pose_off + (cells + 1) * sizeof(uint32_t), 0, slack, c->stream);
+        if (e == hipSuccess)
+            e = hipMemsetAsync((char *)c->d_seg_off + (cells + 1) * sizeof(uint32_t), 0, slack, c->stream);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(c->d_pose_idx, 0, std::max<size_t>(full, 1) * sizeof(uint16_t) + slack, c->stream);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(c->d_seg_idx, 0, std::max<size_t>(full, 1) * sizeof(uint16_t) + slack, c->stream);
+        if (e == hipSuccess)
+        {
+            launch_prune_lists(c->d_quads, c->d_cell_off, c->d_cell_idx, pa, c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, d_totals, 0, c->stream);
+            launch_prune_lists(c->d_quads, c->d_cell_off, c->d_cell_idx, pa, c->d_pose_off, c->d_pose_idx, c->d_seg_off, c->d_seg_idx, d_totals, 1, c->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_totals);
+        if (e != hipSuccess)
+            return hip_fail(c, e, "list pruning");
+        c->n_pose_entries = (size_t)totals[0], c->n_seg_entries = (size_t)totals[1];
+        if (std::getenv("HYAS_CHECK_PRUNE")) // test aid: the host form of the same rules must give the same lists
+        {
+            std::vector<uint32_t> pose_off, seg_off, g_pose_off(cells + 1), g_seg_off(cells + 1);
+            std::vector<uint16_t> pose_idx, seg_idx;
+            prune_lists(m, c->quads.data(), c->cell_off.data(), c->cell_idx.data(), lmax, pose_off, pose_idx, seg_off, seg_idx);
+            std::vector<uint16_t> g_pose_idx(pose_idx.size()), g_seg_idx(seg_idx.size());
+            bool same = pose_idx.size() == totals[0] && seg_idx.size() == totals[1];
+            if (same)
+            {
+                HYAS_HIP(c, hipMemcpy(g_pose_off.data(), c->d_pose_off, (cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                HYAS_HIP(c, hipMemcpy(g_seg_off.data(), c->d_seg_off, (cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if (!pose_idx.empty())
+                    HYAS_HIP(c, hipMemcpy(g_pose_idx.data(), c->d_pose_idx, pose_idx.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+                if (!seg_idx.empty())
+                    HYAS_HIP(c, hipMemcpy(g_seg_idx.data(), c->d_seg_idx, seg_idx.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+                same = g_pose_off == pose_off && g_seg_off == seg_off && g_pose_idx == pose_idx && g_seg_idx == seg_idx;
+            }
+            if (!same)
+                return c->fail(HYAS_ESTATE, "HYAS_CHECK_PRUNE: the pruned lists of the GPU differ from the host form's");
+        }
         m.seg_lmax = std::getenv("HYAS_NO_PRUNE") ? 0.f : lmax;
-        c->n_pose_entries = pose_idx.size(), c->n_seg_entries = seg_idx.size();
     }
 
+    mark("list pruning");
     // footprint lists
     fpt::build(c->P, c->fp);
     if ((rc = upload(c, c->d_fp, c->fp)) != HYAS_OK)
         return rc;
+    mark("footprint table (host) and upload");
 
     // heuristic-table axes: the float accumulators of src/lookup_table.cpp:197-222
     c->tab_xs.clear(), c->tab_ys.clear(), c->tab_ts.clear();
@@ -1250,6 +1318,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     m.table = c->d_table, m.table_size = c->table_size;
     m.table_miss = table_miss_of(c->P.curve_type);
     c->have_map = true;
+    mark("table axes, shot samples, footprint forms");
 
     if (build_table)
     {

@@ -76,6 +76,18 @@ void launch_range_bins(const DevMap &m, const Quad *quads, uint32_t n_quads, con
 // pass 0: off[0..w*h] = offsets of the lists, *total = their sum; pass 1: idx filled (total entries).
 void launch_in_range_lists(const DevMap &m, const Quad *quads, const float *xs, const float *ys, uint32_t nys, float range, const uint32_t *owner,
                            RangeBins bins, uint32_t *off, uint16_t *idx, unsigned long long *total, int pass, hipStream_t s);
+// Exact pruning of the per-key lists on the GPU (hyas_prune.h states the rules): pass 0 leaves the offsets in
+// pose_off / seg_off (cells + 1 entries each) and the two totals in totals2[0..1]; pass 1 fills pose_idx / seg_idx,
+// which hold at most as many entries as the full lists.
+struct PruneArgs
+{
+    double res, ox, oy;
+    double diag, reach; // growth of the cell box for the pose list and for the segment list
+    double lmax, slack; // the ray-only rule of the segment list
+    uint32_t w, cells;
+};
+void launch_prune_lists(const Quad *quads, const uint32_t *cell_off, const uint16_t *cell_idx, const PruneArgs &a, uint32_t *pose_off, uint16_t *pose_idx,
+                        uint32_t *seg_off, uint16_t *seg_idx, unsigned long long *totals2, int pass, hipStream_t s);
 void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,
                            float *out, hipStream_t s);
 void launch_min_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float *out, hipStream_t s);

@@ -549,6 +549,46 @@ __global__ void __launch_bounds__(256) k_in_range_lists(const Quad *__restrict__
     }
 }
 
+// Exact pruning of the per-key lists (what hyas_prune.h does on the host, same arithmetic in double): per key the
+// entries whose quad can still take part in a pose test (pose list) or in a swept-segment test (segment list; entries
+// that only the ray-casting inside test can reach carry bit 15).  One thread per key; FILL = false counts
+// (pose_off[key], seg_off[key] = lengths), FILL = true writes the ids behind the offsets.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_prune_lists(const Quad *__restrict__ quads, const uint32_t *__restrict__ cell_off,
+                                                     const uint16_t *__restrict__ cell_idx, PruneArgs a, uint32_t *__restrict__ pose_off,
+                                                     uint16_t *__restrict__ pose_idx, uint32_t *__restrict__ seg_off, uint16_t *__restrict__ seg_idx)
+{
+    for (size_t key = blockIdx.x * (size_t)blockDim.x + threadIdx.x; key < a.cells; key += (size_t)gridDim.x * blockDim.x)
+    {
+        const double x0 = a.ox + a.res * (double)(key % a.w), y0 = a.oy + a.res * (double)(key / a.w);
+        const double x1 = x0 + a.res, y1 = y0 + a.res;
+        uint32_t np = FILL ? pose_off[key] : 0u, ns = FILL ? seg_off[key] : 0u;
+        for (uint32_t k = cell_off[key]; k < cell_off[key + 1]; ++k)
+        {
+            const uint16_t qi = cell_idx[k];
+            const float4 box = *reinterpret_cast<const float4 *>(&quads[qi].xmin); // xmin, ymin, xmax, ymax
+            const double xmin = box.x, ymin = box.y, xmax = box.z, ymax = box.w;
+            const bool pose = !(xmax < x0 - a.diag || xmin > x1 + a.diag || ymax < y0 - a.diag || ymin > y1 + a.diag);
+            const bool seg = !(xmax < x0 - a.reach || xmin > x1 + a.reach || ymax < y0 - a.reach || ymin > y1 + a.reach);
+            const bool ray = !seg && !(ymax < y0 - a.lmax - a.slack || ymin > y1 + a.lmax + a.slack) && xmax >= x0 - a.lmax - a.slack;
+            if (pose)
+            {
+                if (FILL)
+                    pose_idx[np] = qi;
+                ++np;
+            }
+            if (seg || ray)
+            {
+                if (FILL)
+                    seg_idx[ns] = seg ? qi : (uint16_t)(qi | 0x8000);
+                ++ns;
+            }
+        }
+        if (!FILL)
+            pose_off[key] = np, seg_off[key] = ns;
+    }
+}
+
 // In-place exclusive prefix sum of v[0..n) with the total in v[n] and, as 64 bits, in *total.  One workgroup of 1024
 // lanes, four entries per lane and pass.
 __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(uint32_t *__restrict__ v, size_t n, unsigned long long *__restrict__ total)
@@ -2360,6 +2400,22 @@ void launch_in_range_lists(const DevMap &m, const Quad *quads, const float *xs, 
     }
     else
         hipLaunchKernelGGL(k_in_range_lists<true>, dim3(grid), dim3(256), 0, s, quads, xs, ys, nys, owner, m.w, cells, range, bins, off, idx);
+}
+
+void launch_prune_lists(const Quad *quads, const uint32_t *cell_off, const uint16_t *cell_idx, const PruneArgs &a, uint32_t *pose_off, uint16_t *pose_idx,
+                        uint32_t *seg_off, uint16_t *seg_idx, unsigned long long *totals2, int pass, hipStream_t s)
+{
+    if (a.cells == 0)
+        return;
+    const int grid = grid_for(a.cells, 256, 256 * 32);
+    if (pass == 0)
+    {
+        hipLaunchKernelGGL(k_prune_lists<false>, dim3(grid), dim3(256), 0, s, quads, cell_off, cell_idx, a, pose_off, pose_idx, seg_off, seg_idx);
+        hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, pose_off, (size_t)a.cells, totals2);
+        hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, seg_off, (size_t)a.cells, totals2 + 1);
+    }
+    else
+        hipLaunchKernelGGL(k_prune_lists<true>, dim3(grid), dim3(256), 0, s, quads, cell_off, cell_idx, a, pose_off, pose_idx, seg_off, seg_idx);
 }
 
 void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,

@@ -1,4 +1,5 @@
-// hyas_prune.h -- exact pruning of the per-key obstacle lists (host side).
+// hyas_prune.h -- exact pruning of the per-key obstacle lists: the rules, and their host form (k_prune_lists is the
+// device form the product runs; the host form checks it and serves the host-side tests).
 #pragma once
 #include <cmath>
 #include <vector>
@@ -21,14 +22,27 @@ namespace hyas
 //    quads failing that too are dropped.
 // A point maps to cell (col,row) when round((v-o)/res*1000)/1000 floors to it,
 // i.e. it can sit up to 0.0005 cells outside; `slack` covers that and rounding.
+// The growths and margins of the rules below, for a map and a longest segment extent lmax.
+struct PruneMargins
+{
+    double slack, diag, reach;
+};
+inline PruneMargins prune_margins(const DevMap &m, float lmax)
+{
+    PruneMargins p;
+    p.slack = 0.01 * m.res + 1e-3;
+    p.diag = std::sqrt((double)m.veh_len * m.veh_len + (double)m.veh_wid * m.veh_wid) + p.slack;
+    p.reach = (double)lmax + m.half_wid + (double)m.cull_margin + p.slack;
+    return p;
+}
+
 inline void prune_lists(const DevMap &m, const Quad *quads, const uint32_t *cell_off, const uint16_t *cell_idx, float lmax,
                         std::vector<uint32_t> &pose_off, std::vector<uint16_t> &pose_idx, std::vector<uint32_t> &seg_off,
                         std::vector<uint16_t> &seg_idx)
 {
     const size_t cells = (size_t)m.w * m.h;
-    const double res = m.res, slack = 0.01 * res + 1e-3;
-    const double diag = std::sqrt((double)m.veh_len * m.veh_len + (double)m.veh_wid * m.veh_wid) + slack;
-    const double reach = (double)lmax + m.half_wid + (double)m.cull_margin + slack;
+    const PruneMargins pm = prune_margins(m, lmax);
+    const double res = m.res, slack = pm.slack, diag = pm.diag, reach = pm.reach;
     pose_off.assign(cells + 1, 0), seg_off.assign(cells + 1, 0);
     pose_idx.clear(), seg_idx.clear();
     for (size_t key = 0; key < cells; ++key)

@@ -128,6 +128,25 @@ def test_in_range_lists_from_tile_bins_on_a_large_map(monkeypatch):
     assert np.array_equal(binned.collision(xyt), exhaustive.collision(xyt))
 
 
+def test_pruned_lists_from_the_gpu_equal_the_host_form(monkeypatch):
+    """The pose and segment lists (entries of the in-range lists that can still change a verdict) are cut on the GPU.
+    With HYAS_CHECK_PRUNE the library also runs the host form of the same rules (hyas_prune.h, the form the CPU tests
+    compare with the oracle's verdicts) and fails hyas_set_costmap when offsets or entries differ."""
+    monkeypatch.setenv("HYAS_CHECK_PRUNE", "1")
+    rng = np.random.default_rng(2)
+    big = np.zeros((600, 800), np.uint8)
+    big[rng.random((600, 800)) < 0.03] = 254
+    cases = [(orc.load_map("map_maze"), 1.0, 0.0, 0.0, {}), (orc.load_map("map_parking"), 1.0, 0.0, 0.0, dict(map_boundary_obstacle=1)),
+             (orc.load_map("map_large"), 1.0, 0.0, 0.0, dict(vehicle_length=4.5, vehicle_width=2.0)),
+             (_random_costmap(96, 70, 5), 0.5, -7.25, 3.5, dict(obstacle_detection_range=2.5)), (big, 1.0, 0.0, 0.0, {}),
+             (_random_costmap(64, 48, 9), 2.0, 10.0, -30.0, {})]
+    for m, res, ox, oy, kw in cases:
+        _, ph = _params(position_resolution=1, **kw)
+        h = Hyas(ph)
+        h.set_costmap(m, res, ox, oy, build_table=False)  # raises when the lists differ
+        h.close()
+
+
 def test_map_boundary_obstacle(oracle_built):
     """map_boundary_obstacle = 1 (CollisionDetection::AddMapBoundaryAsObstacle, src/collisiondetection.cpp:1223-1240):
     four rectangles around the grid, in cells whatever resolution and origin are, join the obstacle polygons behind the
