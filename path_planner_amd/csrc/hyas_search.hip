@@ -785,7 +785,9 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     // turns it off; the answers are the same either way, the host then sees every traversable successor.
     const bool filter_on = !(std::getenv("HYAS_FILTER") && std::atoi(std::getenv("HYAS_FILTER")) == 0);
     const size_t cells3d = (size_t)(c->P.headings + 1) * m.w * m.h + m.w + 1;
-    size_t chunk_cap = 8192;
+    // queries per chunk: 4096 (the host state of the live searches -- open lists, cell maps, duplicate hashes -- is what
+    // the worker threads miss the caches on; map_large: 5700-5800 queries/s against 5150-5200 with chunks of 8192)
+    size_t chunk_cap = 4096;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
@@ -797,11 +799,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     }
     if (const char *e = std::getenv("HYAS_CHUNK"))
         chunk_cap = std::max<size_t>(1, (size_t)std::atoll(e));
-    // Query groups in flight at once, two per driver thread, so that a driver does the host part of one group while
-    // the kernel of its other group runs.  A process has four hardware queues and kernels that share one run one
-    // after the other: chunks of up to 2048 queries form four groups (a queue each, two drivers with half of the
-    // worker threads each); larger chunks sixteen groups and eight drivers, where the host part outweighs the queueing
-    // (map_large, 65 536 queries: 4456 queries/s against 4059 with eight groups and four drivers).
+    // Query groups in flight at once.  A process has four hardware queues and kernels that share one run one after the
+    // other: chunks of up to 4096 queries form four groups (a queue each), larger ones (HYAS_CHUNK) eight.
     size_t n_groups = 0; // 0: by chunk size
     if (const char *e = std::getenv("HYAS_GROUPS"))
         n_groups = std::min<size_t>(HYAS_MAX_GROUPS, std::max<size_t>(1, (size_t)std::atoll(e)));
@@ -1113,7 +1112,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 nxt.rc = prepare(nxt, true);
             });
         }
-        const size_t want_groups = n_groups ? n_groups : (cn <= 2048 ? 4 : 8); // measured on map_large: 8 groups 5300 queries/s, 16 groups 4100-4700
+        const size_t want_groups = n_groups ? n_groups : (cn <= 4096 ? 4 : 8);
         const int ng = (int)std::max<size_t>(1, std::min<size_t>(want_groups, cn / 32 + 1));
         const size_t gcap = (cn + ng - 1) / ng; // queries per group
         const size_t gslots = group_slots(gcap, (size_t)ng); // node slots per group

@@ -21,7 +21,9 @@ timeout -k 10 300 python3 -u bench.py --workload footprint_checks > gpurun_out/m
 timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 1 > gpurun_out/meas/extra_table_pr1.json
 timeout -k 10 300 python3 -u bench.py --workload rs_table --table-pr 10 > gpurun_out/meas/extra_table_pr10.json
 echo "extras done"
-HYAS_TRACE=1 timeout -k 10 600 python3 -u bench.py --workload queries_large --steps 1 --warmup 0 > gpurun_out/meas/extra_queries_large.json 2> gpurun_out/meas/extra_queries_large.log
+timeout -k 10 600 python3 -u bench.py --workload queries_large --steps 1 --warmup 0 > gpurun_out/meas/extra_queries_large.json
+# the same once more with the trace's timers on (they cost a few per cent): what the chunks spend where
+HYAS_TRACE=1 timeout -k 10 600 python3 -u bench.py --workload queries_large --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/meas/extra_queries_large_traced.json 2> gpurun_out/meas/extra_queries_large.log
 echo "large done"
 timeout -k 10 300 python3 -u bench.py --workload single_query > gpurun_out/meas/extra_single_query.json
 timeout -k 10 400 python3 -u bench.py --workload modes > gpurun_out/meas/extra_modes.json
