@@ -2649,8 +2649,16 @@ void launch_shot_path(const DevMap &m, const StepIn *nodes, uint32_t n, const hy
 }
 
 // Plans the launch of k_flood for maps of n_cells cells: how many workgroups (= workspace slots), how much LDS, and
-// which variant.  Cells live in LDS when {cost, parent | state} of every cell plus a queue of at least 256 entries fit;
-// the queue gets what is left of an equal share of the compute unit's LDS, so that several queries run per unit.
+// which variant.  A query's flood is one serial chain of queue moves on one wave, so what the launch takes is the
+// chain's latency times the number of queries a compute unit has to take one after the other.  Cell state
+// {cost, parent | state} in LDS gives the shortest chain (map_large: 24.4 ms per query) but leaves room for one to
+// eight queries per unit; with the cell state in the workspace (L2-resident) the chain is 7 % longer for one query per
+// unit and 57 % longer for sixteen, and sixteen queries per unit run side by side (4096 map_large floods: 193 ms with
+// the cells in LDS, 38 ms without).  So: cells in LDS while all queries of the call fit the units at once that way,
+// otherwise cells in the workspace and as many queries per unit as the call needs, at most sixteen; the queue gets
+// what is left of an equal share of the unit's LDS (spill area beyond).  max_per_cu > 0 caps the queries per unit
+// (floods that run beside another chunk's rounds).  HYAS_FLOOD_CELLS_IN_HBM=<k> forces the workspace form with k
+// queries per unit (test knob).
 FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override, int max_per_cu)
 {
     FloodPlan fp{};
@@ -2660,29 +2668,36 @@ FloodPlan plan_flood(uint32_t n_cells, uint32_t n_queries, int heap_cap_override
     fp.cells_pad = (n_cells + 7u) & ~7u;
     const size_t cell_bytes = (size_t)fp.cells_pad * (4 + ps);
     const size_t lds_total = 160 * 1024, margin = 1024;
-    fp.cells_in_lds = false;
-    int per_cu = 1;
+    const int cap = max_per_cu > 0 ? max_per_cu : 16;
+    int per_cu = 0;
     size_t heap_cap = 1024;
     for (int k : {8, 4, 2, 1})
     {
-        if (max_per_cu > 0 && k > max_per_cu)
+        if (k > cap)
             continue;
         const size_t budget = lds_total / k - margin;
         if (cell_bytes + 256 * 16 <= budget)
         {
-            fp.cells_in_lds = true, per_cu = k;
+            per_cu = k;
             heap_cap = std::min<size_t>(1024, (budget - cell_bytes) / 16);
             break;
         }
     }
+    fp.cells_in_lds = per_cu > 0 && (size_t)n_queries <= (size_t)256 * per_cu;
+    const char *force = std::getenv("HYAS_FLOOD_CELLS_IN_HBM");
+    if (force)
+        fp.cells_in_lds = false;
     if (!fp.cells_in_lds)
-        per_cu = 8, heap_cap = 1024;
+    {
+        per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)cap, ((size_t)n_queries + 255) / 256));
+        if (force)
+            per_cu = std::max(1, std::min(32, std::atoi(force)));
+        heap_cap = std::min<size_t>(1024, (lds_total / per_cu - margin) / 16);
+    }
     heap_cap = std::min<size_t>(heap_cap, std::max<uint32_t>(n_cells, 1));
     if (heap_cap_override > 0)
         heap_cap = (size_t)heap_cap_override;
     fp.heap_cap = (uint32_t)heap_cap;
-    if (max_per_cu > 0)
-        per_cu = std::min(per_cu, max_per_cu);
     fp.lds_bytes = heap_cap * 16 + (fp.cells_in_lds ? cell_bytes : 0);
     if (max_per_cu == 1)
         fp.lds_bytes = std::max<size_t>(fp.lds_bytes, lds_total / 2 + margin); // no second workgroup on the unit

@@ -957,6 +957,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         }
     }
 
+    // floods that run beside another chunk's rounds: queries per compute unit at most (HYAS_FLOOD_BESIDE)
+    const int flood_beside = std::getenv("HYAS_FLOOD_BESIDE") ? std::max(1, std::atoi(std::getenv("HYAS_FLOOD_BESIDE"))) : 2; // map_large: 1: 5460-5670 queries/s, 2: 5720-5890, 4: 5680-5870, 8: 5330-5440
     // ---- set-up of one chunk: pose checks, table lookups, 2D floods, start nodes ----
     struct Prep
     {
@@ -1030,7 +1032,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         {
             HYAS_HIP(c, hipMemcpyAsync(ds + o.qlist, qlist, n_flood * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             int frc = flood_dev(c, (const float *)(ds + o.poses), (const uint32_t *)(ds + o.qlist), (uint32_t)n_flood,
-                                c->d_twod + (size_t)P.buf * twod_stride, (float *)(ds + o.startc), st, overlapped ? 1 : 0);
+                                c->d_twod + (size_t)P.buf * twod_stride, (float *)(ds + o.startc), st, overlapped ? flood_beside : 0);
             if (frc != HYAS_OK)
                 return frc;
             HYAS_HIP(c, hipMemcpyAsync(start_cost, ds + o.startc, cn * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -52,7 +52,9 @@ elif what == "flood_large":
     H, W = mp.shape
     h = Hyas(hot_path_params(position_resolution=1, max_iterations=1))
     h.set_costmap(mp, build_table=True)
-    S, G = make_queries(h.collision, 2048, 3, W, H)
+    import os
+
+    S, G = make_queries(h.collision, int(os.environ.get("FLOOD_QUERIES", "2048")), 3, W, H)
     res = h.plan_batch(S, G)
     print(len(res))
 else:

@@ -193,11 +193,11 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
                 dict(HYAS_AHEAD="1", HYAS_AHEAD_WIDTH="4"), dict(HYAS_PIN="0"), dict(HYAS_LIVE_WIDTHS="0"),
                 dict(HYAS_GROUPS="1"), dict(HYAS_GROUPS="7", HYAS_CHUNK="61"),
                 dict(HYAS_TREE="42", HYAS_SPEC="10", HYAS_SPEC_ADAPT="0"), dict(HYAS_TREE="7", HYAS_DEPTH="2"), dict(HYAS_TREE="48", HYAS_SPEC="1"), dict(HYAS_AHEAD="2", HYAS_AHEAD_WIDTH="2", HYAS_SPEC="8"),
-                dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"),
+                dict(HYAS_NODES_IN_HOST_MEMORY="1"), dict(HYAS_FLOOD_HEAP="16", HYAS_CHUNK="64"), dict(HYAS_FLOOD_CELLS_IN_HBM="16"), dict(HYAS_FLOOD_CELLS_IN_HBM="5", HYAS_FLOOD_HEAP="16", HYAS_FLOOD_BESIDE="4"),
                 dict(HYAS_FILTER="0"), dict(HYAS_FILTER="0", HYAS_DEPTH="2"), dict(HYAS_FILTER="1", HYAS_NODES_IN_HOST_MEMORY="1", HYAS_GROUPS="3"),
                 dict(HYAS_FILTER="1", HYAS_CHUNK="50", HYAS_TREE="20"), dict()):
         for k in ("HYAS_SPEC", "HYAS_GROUPS", "HYAS_THREADS", "HYAS_CHUNK", "HYAS_SPEC_ADAPT", "HYAS_SPEC_FLOOR", "HYAS_DRIVERS",
-                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH", "HYAS_PIN", "HYAS_TREE", "HYAS_LIVE_WIDTHS",
+                  "HYAS_NODES_IN_HOST_MEMORY", "HYAS_FLOOD_HEAP", "HYAS_FLOOD_CELLS_IN_HBM", "HYAS_FLOOD_BESIDE", "HYAS_DEPTH", "HYAS_AHEAD", "HYAS_AHEAD_WIDTH", "HYAS_PIN", "HYAS_TREE", "HYAS_LIVE_WIDTHS",
                   "HYAS_FILTER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

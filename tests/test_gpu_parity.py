@@ -259,9 +259,11 @@ def test_flood(parking, maze, monkeypatch):
     """2D cost-to-goal flood (src/hybrid_a_star.cpp:1020-1074) from the GPU kernel against the oracle: goals anywhere
     on the map incl. its corners; with the kernel's open queue held in LDS and with almost all of it pushed out into
     the spill area."""
-    for heap in (None, "8"):
+    for heap, in_hbm in ((None, None), ("8", None), (None, "16"), ("8", "3")):
         if heap:
             monkeypatch.setenv("HYAS_FLOOD_HEAP", heap)
+        if in_hbm:  # cell state in the workspace instead of LDS, that many queries per compute unit
+            monkeypatch.setenv("HYAS_FLOOD_CELLS_IN_HBM", in_hbm)
         for p, seed in ((parking, 31), (maze, 32)):
             goals = list(p.free_poses(5, seed)) + [np.array([0.01, 0.01, 0], np.float32),
                                                    np.array([p.W - 0.01, p.H - 0.01, 1], np.float32),
@@ -274,18 +276,32 @@ def test_flood(parking, maze, monkeypatch):
             a, b = p.o.flood((-5.0, 3.0, 0.0)), p.h.flood((-5.0, 3.0, 0.0))
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         monkeypatch.delenv("HYAS_FLOOD_HEAP", raising=False)
+        monkeypatch.delenv("HYAS_FLOOD_CELLS_IN_HBM", raising=False)
 
 
-def test_flood_large_and_shifted_maps(oracle_built):
-    """The flood on the largest in-tree map (two queries per compute unit's LDS) and on a map with 0.5 m cells and a
-    shifted origin (cell coordinates that are not whole numbers)."""
+def test_flood_large_and_shifted_maps(oracle_built, monkeypatch):
+    """The flood on the largest in-tree map and on a map with 0.5 m cells and a shifted origin (cell coordinates that
+    are not whole numbers), with the cell state in LDS and in the workspace; and a batch large enough for the
+    workspace form to be chosen by itself (sixteen floods per compute unit side by side): every query's start-cell cost
+    enters its start node's h, which the result records of a one-iteration search carry."""
     for name, res, ox, oy in (("map_large", 1.0, 0.0, 0.0), ("map_basic", 0.5, -3.25, 2.5)):
         p = Pair(name, res=res, ox=ox, oy=oy, position_resolution=1)
         rng = np.random.default_rng(5)
-        for _ in range(4):
-            g = (ox + rng.uniform(0, p.W * res), oy + rng.uniform(0, p.H * res), 0.0)
-            a, b = p.o.flood(g), p.h.flood(g)
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, g)
+        for in_hbm in (None, "16"):
+            if in_hbm:
+                monkeypatch.setenv("HYAS_FLOOD_CELLS_IN_HBM", in_hbm)
+            for _ in range(4):
+                g = (ox + rng.uniform(0, p.W * res), oy + rng.uniform(0, p.H * res), 0.0)
+                a, b = p.o.flood(g), p.h.flood(g)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, g, in_hbm)
+            monkeypatch.delenv("HYAS_FLOOD_CELLS_IN_HBM", raising=False)
+    p = Pair("map_large", position_resolution=1, max_iterations=40)
+    xyt, goals = p.free_poses(1200, 61), p.free_poses(1200, 62)
+    res = p.h.plan_batch(xyt, goals)
+    for i in range(0, 1200, 9):
+        r, path, exp = p.o.plan(xyt[i], goals[i])
+        assert r.tobytes() == res[i].tobytes(), (i, r, res[i])
+        assert np.array_equal(exp, p.h.expanded(i)) and path.tobytes() == p.h.path(i).tobytes(), i
 
 
 def _nodes(p, n, seed):
