@@ -130,6 +130,9 @@ def parse_args(argv=None):
                     help="weak: every GPU gets --queries queries; strong: the batch is split into contiguous blocks "
                          "(default: weak for queries_maze, strong for queries_large and rs_table)")
     ap.add_argument("--table-pr", type=int, default=1, help="rs_table: position_resolution (1 or 10)")
+    ap.add_argument("--no-large", dest="with_large", action="store_false", default=True,
+                    help="queries_maze: leave out the one pass of the map_large strong-scaling batch (65 536 queries over all GPUs) "
+                         "that the line otherwise carries as `queries_large_strong`")
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, join the process group (gloo) and aggregate placeholder counts without touching a GPU")
     return ap.parse_args(argv)
@@ -317,6 +320,14 @@ def main():
             cpu = cpu_baseline(map_arr, starts, goals)
             cpu_all = cpu_baseline_all_cores(map_arr, starts, goals)
 
+    # the batched-query strong-scaling workload beside the line's own metric (every rank takes part)
+    curve = None
+    if args.with_large:
+        import bench_extra
+
+        ctx.close()
+        curve = bench_extra.north_star_curve(torch, dist, rank, local_rank, world)
+
     if rank == 0:
         # what the timed steps answered; for the workload as defined (1024 queries, seed 20250228) the GPU test
         # tests/test_gpu_fullsize.py::test_maze_1024_queries_properties compares every query of this very batch with
@@ -359,6 +370,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
+            "queries_large_strong": curve,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -256,13 +256,12 @@ def _round_kernel_roofline(ctx, calls, what):
                     "(bench.py algorithmic_bytes), every node a launch processed counted; no counter pass for this workload"}
 
 
-def queries_large(args):
-    torch, dist, rank, local_rank, world = _dist_setup()
+def queries_large_run(torch, dist, rank, local_rank, world, total_q, scaling, warmup, steps):
+    """The map_large batch on an initialised process group: every rank plans its block (strong) or its own total_q
+    queries (weak); returns the aggregated time and counters and rank-local objects for the caller's extras."""
     from path_planner_amd import Hyas, hot_path_params
     from path_planner_amd.sharding import aggregate, load_map, make_queries, query_shard
 
-    scaling = args.scaling or "strong"
-    total_q = args.queries if args.queries != 1024 else 65536
     mp = load_map("map_large")
     H, W = mp.shape
     ctx = Hyas(hot_path_params(), device=local_rank)
@@ -273,18 +272,38 @@ def queries_large(args):
         starts, goals = starts[b:e], goals[b:e]
     else:
         starts, goals = make_queries(ctx.collision, total_q, 3 + 7919 * rank, W, H)  # total_q queries per GPU
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ctx.plan_batch(starts[: min(len(starts), 2048)], goals[: min(len(goals), 2048)])
     _barrier(torch, dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = ctx.plan_batch(starts, goals)
     _barrier(torch, dist)
     local_s = time.perf_counter() - t0
-    kms, kl = ctx.kernel_ms(0)
-    succ = float(res["successors"].sum()) * args.steps
-    expd = float(res["nodes_expanded"].sum()) * args.steps
-    total_s, (succ, expd, nq) = aggregate(dist, local_s, [succ, expd, float(len(res)) * args.steps])
+    succ = float(res["successors"].sum()) * steps
+    expd = float(res["nodes_expanded"].sum()) * steps
+    total_s, (succ, expd, nq) = aggregate(dist, local_s, [succ, expd, float(len(res)) * steps])
+    return dict(total_s=total_s, succ=succ, expd=expd, nq=nq, res=res, ctx=ctx, starts=starts, goals=goals, mp=mp)
+
+
+def north_star_curve(torch, dist, rank, local_rank, world, total_q=65536):
+    """One pass of the batched-query strong-scaling workload (total_q map_large queries in contiguous blocks over the
+    ranks), for the default bench line to carry beside its own metric.  Every rank must call it."""
+    r = queries_large_run(torch, dist, rank, local_rank, world, total_q, "strong", 1, 1)
+    r["ctx"].close()
+    if rank != 0:
+        return None
+    return {"workload": f"map_large 180x60, {total_q} queries in contiguous blocks over {world} GPU(s), Reeds-Shepp shot every pop; one pass",
+            "scaling": "strong", "seconds": r["total_s"], "queries_per_s": r["nq"] / r["total_s"], "successors_per_s": r["succ"] / r["total_s"],
+            "nodes_expanded_per_s": r["expd"] / r["total_s"]}
+
+
+def queries_large(args):
+    torch, dist, rank, local_rank, world = _dist_setup()
+    scaling = args.scaling or "strong"
+    total_q = args.queries if args.queries != 1024 else 65536
+    r = queries_large_run(torch, dist, rank, local_rank, world, total_q, scaling, args.warmup, args.steps)
+    total_s, succ, expd, nq, res, ctx, starts, goals, mp = (r[k] for k in ("total_s", "succ", "expd", "nq", "res", "ctx", "starts", "goals", "mp"))
     if rank != 0:
         return None
     status = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}

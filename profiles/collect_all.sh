@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/meas
 timeout -k 10 400 python3 -u bench.py > gpurun_out/meas/bench_line.json
 echo "bench done"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/meas/prof -o bench --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/meas/bench_under_rocprof.json 2> gpurun_out/meas/rocprof.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/meas/prof -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-large > gpurun_out/meas/bench_under_rocprof.json 2> gpurun_out/meas/rocprof.log
 cp gpurun_out/meas/prof/bench_kernel_stats.csv gpurun_out/meas/kernel_stats.csv
 rm -rf gpurun_out/meas/prof
 echo "kernel stats done"

@@ -9,7 +9,7 @@ out=${1:-gpurun_out/meas}
 mkdir -p "$out"
 timeout -k 10 400 python3 -u bench.py > "$out/bench_line.json" 2> "$out/bench_line.err"
 echo "bench done"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$out/prof" -o bench --output-format csv -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/rocprof.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$out/prof" -o bench --output-format csv -- python3 bench.py --no-cpu-baseline --no-large > "$out/bench_under_rocprof.json" 2> "$out/rocprof.err"
 cp "$out/prof/bench_kernel_stats.csv" "$out/bench_kernel_stats.csv"
 rm -rf "$out/prof"
 echo "kernel stats done"
