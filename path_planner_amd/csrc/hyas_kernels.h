@@ -104,9 +104,6 @@ void launch_expand(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goa
                    hyas_succ *succ, unsigned long long *stats, int stats_mode, hipStream_t s);
 void launch_shot(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const double *seg_tab, uint32_t seg_cap,
                     uint8_t *shot_ok, float *shot_len, unsigned long long *stats, int stats_mode, hipStream_t s);
-// stores `value` into *flag (pinned host memory) once everything launched on `s` before it has finished: the host spins on
-// the word instead of asking the runtime (hipStreamQuery answers about 10 us later than the word arrives)
-void launch_flag(uint32_t *flag, uint32_t value, hipStream_t s);
 hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode);
 void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal *goals, const float *twod, const double *seg_tab,
                   uint32_t seg_cap, uint8_t *shot_ok, float *shot_len, uint8_t *count, hyas_succ *succ, unsigned long long *stats,

@@ -819,12 +819,6 @@ __global__ void __launch_bounds__(256) k_table_lookup(DevMap m, const float *__r
         cost[i] = table_cost(m, xyt[3 * i], xyt[3 * i + 1], xyt[3 * i + 2]);
 }
 
-__global__ void __launch_bounds__(64) k_flag(uint32_t *flag, uint32_t value)
-{
-    if (threadIdx.x == 0)
-        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ void __launch_bounds__(256) k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -2591,9 +2585,6 @@ hipError_t resolve_round_kernel(const DevMap &m, bool stats, int stats_mode)
         mode = 0;
     hipError_t e = hipSuccess;
     dispatch_mode_curve<ResolveRound>(m, mode, &e);
-    hipFuncAttributes attr;
-    if (e == hipSuccess)
-        e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_flag));
     return e;
 }
 
@@ -2620,8 +2611,6 @@ void launch_round(const DevMap &m, const StepIn *in, uint32_t n, const hyas_goal
     dispatch_mode_curve<LaunchRound>(m, mode, in, n, goals, twod, seg_tab, seg_cap, shot_ok, shot_len, count, succ, stats, child,
                                      (child_shoot ? ROUND_CHILD_SHOOT : 0u) | ROUND_TAG_CANDIDATE, filter, out, s);
 }
-
-void launch_flag(uint32_t *flag, uint32_t value, hipStream_t s) { hipLaunchKernelGGL(k_flag, dim3(1), dim3(64), 0, s, flag, value); }
 
 void launch_bezier_points(const float *anchors, const uint32_t *first, const uint32_t *off, const uint32_t *n, uint32_t n_curves, float *out, hipStream_t s)
 {

@@ -731,7 +731,7 @@ int host_threads()
 } // namespace
 
 // Worker threads of the search driver, kept in the context between calls: one pool for the set-up and finishing
-// steps of a chunk, and one per driver thread for the rounds.  Idle workers block after a short spin.
+// steps of a chunk, and one for the rounds.  Idle workers block after a short spin.
 struct SearchPools
 {
     std::unique_ptr<Pool> main;
@@ -771,7 +771,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     c->expanded.assign(n, std::vector<int32_t>());
     if (n == 0)
         return HYAS_OK;
-    // the round kernel is looked up here, once, before several driver threads launch it at the same moment
+    // the round kernel is looked up here, once, before several worker threads launch it at the same moment
     HYAS_HIP(c, resolve_round_kernel(m, c->stats_on, c->stats_mode));
     if (!c->pools)
         c->pools = new SearchPools();
