@@ -662,15 +662,24 @@ RS_HD void offer_any_of_equals(FamilyBest &b, bool ok, double L, double total)
 }
 // atan2(y, x) is certainly below -RS_ZERO
 RS_HD bool angle_is_negative(double y, double x) { return y < 0. && !(-y <= RS_DEAD * x); }
-// mod2pi(atan2(ay, ax) + atan2(by, bx)) is certainly below -RS_ZERO: the sum is the angle of the product of
-// (ax + i ay) and (bx + i by), whose imaginary part is ax by + ay bx.  Where that is negative by more than 1e-13 of
-// (|ax| + |ay|)(|bx| + |by|) -- a bound of the product's modulus and, times 1e-15, of the rounding in it -- the true
-// angle lies inside (-pi + 1e-13, -1e-13), and the computed one, a few 1e-16 away, is folded to the same side.
-RS_HD bool angle_sum_is_negative(double ay, double ax, double by, double bx)
+// Sums and differences of such angles are the angle of a product of complex numbers: atan2(ay, ax) + atan2(by, bx) is
+// that of (ax + i ay)(bx + i by), minus an angle is the conjugate, and phi itself is (cos phi, sin phi).  Where the
+// product's imaginary part is negative (positive) by more than 1e-13 of a bound m of its modulus -- the product of the
+// factors' |re| + |im|, which times a few 1e-16 also bounds the rounding in it -- the true angle lies inside
+// (-pi + 1e-13, -1e-13) (inside (1e-13, pi - 1e-13)), and the computed sum, a few 1e-16 away, is folded by mod2pi to
+// the same side: a form that needs that angle to be >= -RS_ZERO (<= RS_ZERO) is certain to fail.
+struct Product
 {
-    const double im = ax * by + ay * bx, m = (hy_fabs(ax) + hy_fabs(ay)) * (hy_fabs(bx) + hy_fabs(by));
-    return -im > 1e-13 * m;
+    double re, im, m;
+};
+RS_HD Product product(double ar, double ai, double br, double bi)
+{
+    Product c;
+    c.re = ar * br - ai * bi, c.im = ar * bi + ai * br, c.m = (hy_fabs(ar) + hy_fabs(ai)) * (hy_fabs(br) + hy_fabs(bi));
+    return c;
 }
+RS_HD bool clearly_negative(double im, double m) { return -im > 1e-13 * m; }
+RS_HD bool clearly_positive(double im, double m) { return im > 1e-13 * m; }
 
 // The candidates of symmetry s in one frame, (X, Y) being the goal there with the symmetry's signs applied.
 template <bool BACK>
@@ -681,9 +690,15 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
         // forms on (x - sin phi, y - 1 + cos phi): (8.1) forward only, (8.3/8.4) and (8.9) in both frames
         const double xi = ax - sp, eta = ay - 1. + cp;
         const double R = hy_sqrt(xi * xi + eta * eta);
-        // (8.9): t = mod2pi(atan2(eta, xi) + atan2(r, -2))
+        const double reach = 1.5 * (hy_fabs(xi) + hy_fabs(eta)); // bounds |xi + i eta| (|cos phi| + |sin phi|)
+        // (8.1): t = atan2(eta, xi) and v = mod2pi(phi - t), the angle of (cos phi + i sin phi)(xi - i eta), both >= 0
+        const bool first = !BACK && !angle_is_negative(eta, xi) && !clearly_negative(sp * xi - cp * eta, reach);
+        const bool second = R <= 4.;
+        // (8.9): t = mod2pi(atan2(eta, xi) + atan2(r, -2)) >= 0; v = mod2pi(phi - pi/2 - t), the angle of
+        // (sin phi - i cos phi) conj((xi + i eta)(-2 + i r)), <= 0
         const double r = hy_sqrt(R >= 2. ? R * R - 4. : 0.);
-        const bool first = !BACK && !angle_is_negative(eta, xi), second = R <= 4., third = R >= 2. && !angle_sum_is_negative(eta, xi, r, -2.);
+        const Product p9 = product(xi, eta, -2., r);
+        const bool third = R >= 2. && !clearly_negative(p9.im, p9.m) && !clearly_positive(-(sp * p9.im + cp * p9.re), 1.5 * p9.m);
         if (first || second || third)
         {
             const double TH = hy_atan2_q(eta, xi, qa);
@@ -717,7 +732,8 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
     {
         // forms on (x + sin phi, y - 1 - cos phi): (8.10) in both frames, the others forward only
         const double xi = ax + sp, eta = ay - 1. - cp;
-        const bool fourth = !angle_is_negative(xi, -eta); // (8.10): t = atan2(xi, -eta)
+        // (8.10): t = atan2(xi, -eta) >= 0; v = mod2pi(t + pi/2 - phi), the angle of (-xi - i eta)(cos phi - i sin phi), <= 0
+        const bool fourth = !angle_is_negative(xi, -eta) && !clearly_positive(xi * sp - eta * cp, 1.5 * (hy_fabs(xi) + hy_fabs(eta)));
         if (BACK && !fourth)
             return;
         const double R = hy_sqrt(xi * xi + eta * eta);
@@ -733,8 +749,10 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
             return;
         const double u1 = R * R;
         const double SQ = hy_sqrt((u1 >= 4. || R >= 2.) ? u1 - 4. : 0.); // shared by (8.2) and (8.11)
-        // LpSpRp, group 1: t = mod2pi(atan2(eta, xi) + atan2(2, u))
-        if (u1 >= 4. && !angle_sum_is_negative(eta, xi, 2., SQ))
+        // LpSpRp, group 1: t = mod2pi(atan2(eta, xi) + atan2(2, u)) >= 0; v = mod2pi(t - phi), the angle of
+        // (xi + i eta)(u + 2 i)(cos phi - i sin phi), >= 0
+        const Product p2 = product(xi, eta, SQ, 2.);
+        if (u1 >= 4. && !clearly_negative(p2.im, p2.m) && !clearly_negative(p2.im * cp - p2.re * sp, 1.5 * p2.m))
         {
             const double u = SQ;
             const double t = mod2pi_few_turns(hy_atan2_q(eta, xi, qa) + hy_atan2_q(2., u, qa), beyond);
@@ -774,7 +792,8 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
             {
                 // t = mod2pi(atan2(ty, tx)), and mod2pi leaves what atan2 returns as it is
                 const double ty = (4 - u) * xi - 2 * eta, tx = -2 * xi + (u - 4) * eta;
-                if (!angle_is_negative(ty, tx))
+                // ... >= 0; v = mod2pi(t - phi), the angle of (tx + i ty)(cos phi - i sin phi), >= 0
+                if (!angle_is_negative(ty, tx) && !clearly_negative(ty * cp - tx * sp, 1.5 * (hy_fabs(tx) + hy_fabs(ty))))
                 {
                     const double t = hy_atan2_q(ty, tx, qa);
                     const double v = mod2pi_few_turns(t - aphi, beyond);

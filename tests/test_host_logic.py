@@ -103,6 +103,12 @@ def test_side_by_side_reeds_shepp_candidates_equal_the_plain_form(host_geom):
                                  indexing="ij"), -1).reshape(-1, 3)
     tgrid = np.ascontiguousarray(tgrid, np.float64)  # a coarse copy of the table's own grid (origin and axes included)
     assert host_geom.hg_rs_shortest_length_mismatches(tgrid.ctypes.data_as(C.c_void_p), len(tgrid)) == 0
+    # ... and of the 180 x 60 m table at turning radius 0.35 (goals hundreds of radii away: the far field, where most
+    # candidates are dropped by the signs of their arcs)
+    far = np.stack(np.meshgrid(np.arange(0, 180, 1.3) / np.float32(0.35), np.arange(0, 60, 0.9) / np.float32(0.35),
+                               np.arange(0, 73) * np.float32(2 * math.pi / 72), indexing="ij"), -1).reshape(-1, 3)
+    far = np.ascontiguousarray(far, np.float64)
+    assert host_geom.hg_rs_shortest_length_mismatches(far.ctypes.data_as(C.c_void_p), len(far)) == 0
     T = 2 * math.pi
     m = np.concatenate([rng.uniform(-60, 60, 400000), rng.uniform(-1e-9, 1e-9, 100), np.arange(-9, 10) * T, np.nextafter(np.arange(-9, 10) * T, 0),
                         np.nextafter(np.arange(-9, 10) * T, 1e9), [0.0, -0.0, math.pi, -math.pi, 1e9, -1e9, 1e300, np.inf, -np.inf, np.nan]])
