@@ -6,6 +6,7 @@
 //   wrval   launch + hipStreamWriteValue32 into pinned host memory, host spins on the word
 //   flagk   launch + a second one-thread kernel that stores the word (system scope), host spins on the word
 //   tags    launch, host spins until every record carries this round's tag (no completion signal at all)
+//   tagsbar the same with the records in fine-grained device memory, read by the host through the PCIe BAR
 // Prints microseconds per round (median of `rounds`), the launch call's own duration, and for `tags` whether any record
 // was ever seen with a matching tag but a stale payload.
 #include <hip/hip_runtime.h>
@@ -67,17 +68,31 @@ int main(int argc, char **argv)
         std::sort(v.begin(), v.end());
         return v[v.size() / 2];
     };
-    const char *names[5] = {"sync", "query", "wrval", "flagk", "tags"};
-    for (int mode = 0; mode < 5; ++mode)
+    // records in device memory the host can address (large BAR), where there is such memory
+    u32x4 *b_out = nullptr;
+    if (hipExtMallocWithFlags((void **)&b_out, sizeof(u32x4) * blocks, hipDeviceMallocFinegrained) != hipSuccess)
+        (void)hipGetLastError(), b_out = nullptr;
+    if (b_out)
+        CHECK(hipMemset(b_out, 0, sizeof(u32x4) * blocks));
+    const char *names[6] = {"sync", "query", "wrval", "flagk", "tags", "tagsbar"};
+    for (int mode = 0; mode < 6; ++mode)
     {
+        if (mode == 5 && !b_out)
+        {
+            printf("tagsbar no host-addressable device memory\n");
+            continue;
+        }
+        u32x4 *const k_out = mode == 5 ? b_out : d_out;
+        const u32x4 *const r_out = mode == 5 ? b_out : h_out;
+        const int use_rounds = mode == 5 ? std::min(rounds, 100) : rounds; // reads through the BAR take microseconds each
         std::vector<double> total, call;
         long long torn = 0;
         bool supported = true;
-        for (int r = 0; r < rounds + 50 && supported; ++r)
+        for (int r = 0; r < use_rounds + 50 && supported; ++r)
         {
             ++tag;
             const double t0 = now_us();
-            hipLaunchKernelGGL(k_records, dim3(blocks), dim3(256), 0, st, d_out, tag, work);
+            hipLaunchKernelGGL(k_records, dim3(blocks), dim3(256), 0, st, k_out, tag, work);
             if (mode == 2)
             {
                 if (hipStreamWriteValue32(st, d_flag, tag, 0) != hipSuccess)
@@ -102,14 +117,14 @@ int main(int argc, char **argv)
                 while (*(volatile uint32_t *)h_flag != tag)
                     _mm_pause();
             }
-            else
+            else // modes 4 and 5
             {
                 for (int i = 0; i < blocks; ++i)
                 {
                     for (;;)
                     {
                         alignas(16) uint32_t w[4];
-                        _mm_store_si128((__m128i *)w, _mm_load_si128((const __m128i *)(h_out + i))); // one 16-byte load
+                        _mm_store_si128((__m128i *)w, _mm_load_si128((const __m128i *)(r_out + i))); // one 16-byte load
                         if (w[3] == tag)
                         {
                             if (w[0] != tag * 3u + 1u || w[1] != tag * 5u + 2u || w[2] != ((uint32_t)i ^ tag))
@@ -121,12 +136,12 @@ int main(int argc, char **argv)
                 }
             }
             const double t2 = now_us();
-            if (mode == 4) // the stream must have drained before the records are written again
+            if (mode >= 4) // the stream must have drained before the records are written again
                 CHECK(hipStreamSynchronize(st));
             if (r >= 50)
                 total.push_back(t2 - t0), call.push_back(t1 - t0);
             // results the host is about to read must really be this round's
-            if (mode != 4)
+            if (mode < 4)
                 for (int i = 0; i < blocks; i += 97)
                     if (h_out[i][3] != tag)
                         ++torn;
