@@ -682,6 +682,9 @@ RS_HD bool clearly_negative(double im, double m) { return -im > 1e-13 * m; }
 RS_HD bool clearly_positive(double im, double m) { return im > 1e-13 * m; }
 
 // The candidates of symmetry s in one frame, (X, Y) being the goal there with the symmetry's signs applied.
+// Square roots are taken late: the sign tests first run on bounds of the roots they involve -- with
+// R = |xi + i eta| and r = sqrt(R^2 - 4), max(|xi|, |eta|) - 2 <= R - 2 <= r <= R <= |xi| + |eta| -- and a root is only
+// taken for a form those leave alive (the tests are linear in the root, so their extreme over the interval decides).
 template <bool BACK>
 RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, double cp, FamilyBest *fam, bool &beyond, const double *qa)
 {
@@ -689,54 +692,89 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
     {
         // forms on (x - sin phi, y - 1 + cos phi): (8.1) forward only, (8.3/8.4) and (8.9) in both frames
         const double xi = ax - sp, eta = ay - 1. + cp;
-        const double R = hy_sqrt(xi * xi + eta * eta);
-        const double reach = 1.5 * (hy_fabs(xi) + hy_fabs(eta)); // bounds |xi + i eta| (|cos phi| + |sin phi|)
+        const double s2 = xi * xi + eta * eta;
+        const double hi = hy_fabs(xi) + hy_fabs(eta), big = hy_fabs(xi) > hy_fabs(eta) ? hy_fabs(xi) : hy_fabs(eta);
+        const double lo = big > 2. ? big - 2. : 0.;
+        const double reach = 1.5 * hi; // bounds |xi + i eta| (|cos phi| + |sin phi|)
+        const double A = sp * xi - cp * eta, B = sp * eta + cp * xi;
         // (8.1): t = atan2(eta, xi) and v = mod2pi(phi - t), the angle of (cos phi + i sin phi)(xi - i eta), both >= 0
-        const bool first = !BACK && !angle_is_negative(eta, xi) && !clearly_negative(sp * xi - cp * eta, reach);
-        const bool second = R <= 4.;
-        // (8.9): t = mod2pi(atan2(eta, xi) + atan2(r, -2)) >= 0; v = mod2pi(phi - pi/2 - t), the angle of
-        // (sin phi - i cos phi) conj((xi + i eta)(-2 + i r)), <= 0
-        const double r = hy_sqrt(R >= 2. ? R * R - 4. : 0.);
-        const Product p9 = product(xi, eta, -2., r);
-        const bool third = R >= 2. && !clearly_negative(p9.im, p9.m) && !clearly_positive(-(sp * p9.im + cp * p9.re), 1.5 * p9.m);
-        if (first || second || third)
+        const bool first = !BACK && !angle_is_negative(eta, xi) && !clearly_negative(A, reach);
+        // (8.9): t = mod2pi(atan2(eta, xi) + atan2(r, -2)) >= 0, the angle of (xi + i eta)(-2 + i r) with imaginary part
+        // xi r - 2 eta; v = mod2pi(phi - pi/2 - t), the angle of (sin phi - i cos phi) conj(that product) with imaginary
+        // part 2 B - r A, <= 0
+        const double m9 = hi * (2. + hi);
+        bool third = s2 >= 3.5 && !clearly_negative((xi >= 0. ? xi * hi : xi * lo) - 2. * eta, m9) &&
+                     !clearly_positive(2. * B - (A >= 0. ? A * hi : A * lo), 1.5 * m9);
+        if (first || s2 <= 16.5 || third)
         {
-            const double TH = hy_atan2_q(eta, xi, qa);
-            if (first) // LpSpLp, group 0
+            const double R = hy_sqrt(s2);
+            const bool second = R <= 4.;
+            double r = 0.;
+            third = third && R >= 2.;
+            if (third)
             {
-                const double t = TH, u = R;
-                const double v = mod2pi_few_turns(aphi - t, beyond);
-                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-                offer_any_of_equals(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, L, L);
+                r = hy_sqrt(R * R - 4.);
+                const Product p9 = product(xi, eta, -2., r);
+                third = !clearly_negative(p9.im, p9.m) && !clearly_positive(-(sp * p9.im + cp * p9.re), 1.5 * p9.m);
             }
-            if (second) // LpRmL, groups 2 and 3
+            if (first || second || third)
             {
-                const double u = -2. * hy_asin_q(.25 * R, qa);
-                const double t = mod2pi_few_turns(TH + .5 * u + RS_PI, beyond);
-                const double v = mod2pi_few_turns(aphi - t + u, beyond);
-                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-                const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hy_fabs(t) : L;
-                offer(fam[1], t >= -RS_ZERO && u <= RS_ZERO, (BACK ? 12 : 8) + s, L, total);
-            }
-            if (third) // LpRmSmLm, groups 6 and 8
-            {
-                const double u = 2. - r;
-                const double t = mod2pi_few_turns(TH + hy_atan2_q(r, -2., qa), beyond);
-                const double v = mod2pi_few_turns(aphi - .5 * RS_PI - t, beyond);
-                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-                const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hp + hy_fabs(t) : hy_fabs(t) + hp + hy_fabs(u) + hy_fabs(v);
-                offer(fam[3], t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO, (BACK ? 32 : 24) + s, L, total);
+                const double TH = hy_atan2_q(eta, xi, qa);
+                if (first) // LpSpLp, group 0
+                {
+                    const double t = TH, u = R;
+                    const double v = mod2pi_few_turns(aphi - t, beyond);
+                    const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                    offer_any_of_equals(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, L, L);
+                }
+                if (second) // LpRmL, groups 2 and 3
+                {
+                    const double u = -2. * hy_asin_q(.25 * R, qa);
+                    const double t = mod2pi_few_turns(TH + .5 * u + RS_PI, beyond);
+                    const double v = mod2pi_few_turns(aphi - t + u, beyond);
+                    const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                    const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hy_fabs(t) : L;
+                    offer(fam[1], t >= -RS_ZERO && u <= RS_ZERO, (BACK ? 12 : 8) + s, L, total);
+                }
+                if (third) // LpRmSmLm, groups 6 and 8
+                {
+                    const double u = 2. - r;
+                    const double t = mod2pi_few_turns(TH + hy_atan2_q(r, -2., qa), beyond);
+                    const double v = mod2pi_few_turns(aphi - .5 * RS_PI - t, beyond);
+                    const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                    const double total = BACK ? hy_fabs(v) + hy_fabs(u) + hp + hy_fabs(t) : hy_fabs(t) + hp + hy_fabs(u) + hy_fabs(v);
+                    offer(fam[3], t >= -RS_ZERO && u <= RS_ZERO && v <= RS_ZERO, (BACK ? 32 : 24) + s, L, total);
+                }
             }
         }
     }
     {
         // forms on (x + sin phi, y - 1 - cos phi): (8.10) in both frames, the others forward only
         const double xi = ax + sp, eta = ay - 1. - cp;
+        const double hi = hy_fabs(xi) + hy_fabs(eta);
+        const double A = xi * sp - eta * cp;
         // (8.10): t = atan2(xi, -eta) >= 0; v = mod2pi(t + pi/2 - phi), the angle of (-xi - i eta)(cos phi - i sin phi), <= 0
-        const bool fourth = !angle_is_negative(xi, -eta) && !clearly_positive(xi * sp - eta * cp, 1.5 * (hy_fabs(xi) + hy_fabs(eta)));
+        const bool fourth = !angle_is_negative(xi, -eta) && !clearly_positive(A, 1.5 * hi);
         if (BACK && !fourth)
             return;
-        const double R = hy_sqrt(xi * xi + eta * eta);
+        const double s2 = xi * xi + eta * eta;
+        bool second = false, eleventh = false;
+        if (!BACK)
+        {
+            const double big = hy_fabs(xi) > hy_fabs(eta) ? hy_fabs(xi) : hy_fabs(eta);
+            const double lo = big > 2. ? big - 2. : 0., m = hi * (2. + hi), B = xi * cp + eta * sp;
+            // (8.2), with u = sqrt(R^2 - 4): t is the angle of (xi + i eta)(u + 2 i), imaginary part 2 xi + eta u, >= 0;
+            // v = mod2pi(t - phi), that of the product times (cos phi - i sin phi), imaginary part 2 B - u A, >= 0
+            second = s2 >= 3.5 && !clearly_negative(2. * xi + (eta >= 0. ? eta * hi : eta * lo), m) &&
+                     !clearly_negative(2. * B - (A >= 0. ? A * lo : A * hi), 1.5 * m);
+            // (8.11), with the same root (and u = 4 - root <= 0): t is the angle of (xi + i eta)(-2 + i root) but for
+            // roundings, imaginary part root xi - 2 eta, >= 0; v = mod2pi(t - phi), imaginary part root B + 2 A, >= 0
+            eleventh = s2 >= 3.5 && hi >= 3.9 && !clearly_negative((xi >= 0. ? xi * hi : xi * lo) - 2. * eta, m) &&
+                       !clearly_negative(2. * A + (B >= 0. ? B * hi : B * lo), 1.5 * m);
+            if (!(fourth || second || eleventh || s2 <= 20.5))
+                return;
+        }
+        const double R = hy_sqrt(s2);
         if (R >= 2. && fourth) // LpRmSmRm, groups 7 and 9
         {
             const double t = hy_atan2_q(xi, -eta, qa), u = 2. - R;
@@ -748,18 +786,23 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
         if (BACK)
             return;
         const double u1 = R * R;
-        const double SQ = hy_sqrt((u1 >= 4. || R >= 2.) ? u1 - 4. : 0.); // shared by (8.2) and (8.11)
-        // LpSpRp, group 1: t = mod2pi(atan2(eta, xi) + atan2(2, u)) >= 0; v = mod2pi(t - phi), the angle of
-        // (xi + i eta)(u + 2 i)(cos phi - i sin phi), >= 0
-        const Product p2 = product(xi, eta, SQ, 2.);
-        if (u1 >= 4. && !clearly_negative(p2.im, p2.m) && !clearly_negative(p2.im * cp - p2.re * sp, 1.5 * p2.m))
+        double SQ = 0.;
+        if ((second || eleventh) && (u1 >= 4. || R >= 2.))
+            SQ = hy_sqrt(u1 - 4.); // shared by (8.2) and (8.11)
+        // LpSpRp, group 1
+        if (second && u1 >= 4.)
         {
-            const double u = SQ;
-            const double t = mod2pi_few_turns(hy_atan2_q(eta, xi, qa) + hy_atan2_q(2., u, qa), beyond);
-            const double v = mod2pi_few_turns(t - aphi, beyond);
-            const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
-            offer_any_of_equals(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, L, L);
+            const Product p2 = product(xi, eta, SQ, 2.);
+            if (!clearly_negative(p2.im, p2.m) && !clearly_negative(p2.im * cp - p2.re * sp, 1.5 * p2.m))
+            {
+                const double u = SQ;
+                const double t = mod2pi_few_turns(hy_atan2_q(eta, xi, qa) + hy_atan2_q(2., u, qa), beyond);
+                const double v = mod2pi_few_turns(t - aphi, beyond);
+                const double L = hy_fabs(t) + hy_fabs(u) + hy_fabs(v);
+                offer_any_of_equals(fam[0], t >= -RS_ZERO && v >= -RS_ZERO, L, L);
+            }
         }
+        if (s2 <= 4.5) // (8.7) needs R <= 2
         {
             const double rho = .25 * (2. + R);
             if (rho <= 1.) // LpRupLumRm, group 4
@@ -771,6 +814,7 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
                 offer(fam[2], t >= -RS_ZERO && v <= RS_ZERO, 16 + s, L, hy_fabs(t) + hy_fabs(u) + hy_fabs(u) + hy_fabs(v));
             }
         }
+        if (s2 <= 20.5) // (8.8) needs 20 - xi^2 - eta^2 >= 0
         {
             const double rho = (20. - xi * xi - eta * eta) / 16.;
             if (rho >= 0 && rho <= 1) // LpRumLumRp, group 5
@@ -785,7 +829,7 @@ RS_HD void offer_symmetry(int s, double ax, double ay, double aphi, double sp, d
                 }
             }
         }
-        if (R >= 2.) // LpRmSLmRp, group 10
+        if (eleventh && R >= 2.) // LpRmSLmRp, group 10
         {
             const double u = 4. - SQ;
             if (u <= RS_ZERO)
