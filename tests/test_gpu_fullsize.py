@@ -214,6 +214,23 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
             assert np.array_equal(h.path(i), keep[i][0]) and np.array_equal(h.expanded(i), keep[i][1]), (env, i)
 
 
+def test_round_timing_switch(maze_ctx):
+    """hyas_set_round_timing: off (the default) the search rounds carry no timing events and report no kernel time; on,
+    every second launch of a query group is timed and the sum scaled to all launches; the answers are the same."""
+    h = maze_ctx
+    S, G = make_queries(h.collision, 96, 77, 50, 50)
+    h.set_round_timing(0)
+    a = h.plan_batch(S[:96], G[:96])
+    ms0, n0 = h.kernel_ms(0)
+    h.set_round_timing(1)
+    b = h.plan_batch(S[:96], G[:96])
+    ms1, n1 = h.kernel_ms(0)
+    h.set_round_timing(0)
+    assert a.tobytes() == b.tobytes()
+    assert ms0 == 0 and ms1 > 0 and n1 > 0
+    assert 5e-3 < ms1 / n1 < 5.0  # a launch lasts tens of microseconds
+
+
 def test_full_depth_searches_match_oracle(maze_ctx, oracle_built):
     """Searches at the reference's full iteration limit (10 000), where one wrong verdict, cost bit or tie anywhere
     along the way changes everything after it: result records, expansion order and paths against the CPU oracle,
