@@ -449,22 +449,24 @@ inline std::vector<float> sweep_angles()
 // free runs (distance == detection range) and obstacle runs alternate; a run that ends becomes {label, start, width},
 // labelled with the detection range when it was free and with the cell's minimum obstacle distance otherwise; the run
 // still open at the last angle is labelled with the minimum distance whatever its kind.
-inline void ranges_of_sweep(const float *angle, const float *dist, size_t n, float min_distance, float detection_range, std::vector<Range> &out)
+// angle(i), dist(i): the sweep; emit(label, start, width) receives the runs in order.  Host and device.
+template <class AngleAt, class DistAt, class Emit>
+HD void ranges_of_sweep_each(AngleAt angle, DistAt dist, uint32_t n, float min_distance, float detection_range, Emit emit)
 {
-    out.clear();
     float range_start = -1, range_range = -1;
     bool free_flag = false, obstacle_flag = false;
-    for (size_t i = 0; i < n; ++i)
+    const float last = n ? angle(n - 1) : 0.f;
+    for (uint32_t i = 0; i < n; ++i)
     {
-        const float a = angle[i];
-        if (dist[i] == detection_range)
+        const float a = angle(i);
+        if (dist(i) == detection_range)
         {
             if (obstacle_flag)
             {
                 obstacle_flag = false, free_flag = true;
                 range_range = a - range_start;
                 if (range_start != -1 && range_range != -1)
-                    out.push_back(Range{min_distance, range_start, range_range});
+                    emit(min_distance, range_start, range_range);
                 range_start = a;
             }
             if (!free_flag)
@@ -477,34 +479,49 @@ inline void ranges_of_sweep(const float *angle, const float *dist, size_t n, flo
                 free_flag = false, obstacle_flag = true;
                 range_range = a - range_start;
                 if (range_start != -1 && range_range != -1)
-                    out.push_back(Range{detection_range, range_start, range_range});
+                    emit(detection_range, range_start, range_range);
                 range_start = a;
             }
             if (!obstacle_flag)
                 free_flag = false, obstacle_flag = true, range_start = a;
         }
-        if (a == angle[n - 1])
+        if (a == last)
         {
             range_range = a - range_start;
             if (range_start != -1 && range_range != -1 && range_range != 0)
-                out.push_back(Range{min_distance, range_start, range_range});
+                emit(min_distance, range_start, range_range);
         }
     }
 }
-// FindFreeAngleRangeAndObstacleAngleRange (src/collisiondetection.cpp:688-725): every range cut to what it has in
-// common with {0, ConvertDegToRad(359.9999)}; ranges with nothing in common are dropped
+// FindFreeAngleRangeAndObstacleAngleRange (src/collisiondetection.cpp:688-725): a range cut to what it has in
+// common with {0, ConvertDegToRad(359.9999)}; false: nothing in common, the range is dropped
+HD bool cut_range_to_circle(Range &r)
+{
+    float s, w;
+    common_range(r.start, r.range, 0.f, deg2rad(359.9999f), s, w);
+    if (s == -1 || w == -1)
+        return false;
+    r.start = s, r.range = w;
+    return true;
+}
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline void ranges_of_sweep(const float *angle, const float *dist, size_t n, float min_distance, float detection_range, std::vector<Range> &out)
+{
+    out.clear();
+    ranges_of_sweep_each([&](uint32_t i) { return angle[i]; }, [&](uint32_t i) { return dist[i]; }, (uint32_t)n, min_distance, detection_range,
+                         [&](float label, float start, float width) { out.push_back(Range{label, start, width}); });
+}
 inline void cut_to_circle(std::vector<Range> &v)
 {
-    const float s2 = 0, r2 = deg2rad(359.9999f);
     size_t k = 0;
     for (size_t i = 0; i < v.size(); ++i)
     {
-        float s, r;
-        common_range(v[i].start, v[i].range, s2, r2, s, r);
-        if (s != -1 && r != -1)
-            v[k++] = Range{v[i].dist, s, r};
+        Range r = v[i];
+        if (cut_range_to_circle(r))
+            v[k++] = r;
     }
     v.resize(k);
 }
+#endif
 } // namespace ad
 } // namespace hyas

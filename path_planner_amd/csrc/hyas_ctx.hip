@@ -888,74 +888,70 @@ int hyas_table_install_noalloc_dev(hyas_ctx *c, int curve, const float *raw_dev)
 }
 
 // The per-costmap part of the adaptive step size / steering modes: the hybrid_astar branch of
-// CollisionDetection::UpdateGrid (src/collisiondetection.cpp:39-46).  The sweep of every cell corner (361 rays against
-// the corner's in-range obstacles) and the minimum obstacle distance run on the GPU in tiles of whole x columns; the
-// run-length pass over each sweep, the cut to the circle and the density normalisation are a few operations per
-// angle and run here.  owner[key] = the first loop position (x outer, y inner) that maps to a grid key: the
-// reference's maps keep what that position emplaced.
-static int build_adaptive_maps(hyas_ctx *c, const std::vector<float> &xs, const std::vector<float> &ys, const std::vector<int64_t> &owner)
+// CollisionDetection::UpdateGrid (src/collisiondetection.cpp:39-46).  For every grid key the minimum obstacle distance,
+// the sweep of its owner corner (361 rays against the corner's in-range obstacles), the run-length pass over the sweep
+// and the cut to the circle run in one kernel (k_adaptive_ranges: lengths, prefix sum, ranges); the density
+// normalisation is two passes over the list lengths here.  owner[key] = the first loop position (x outer, y inner)
+// that maps to a grid key: the reference's maps keep what that position emplaced.  The host keeps copies for
+// hyas_adaptive_cell.
+static int build_adaptive_maps(hyas_ctx *c, const float *d_xs, const float *d_ys, uint32_t nys, const uint32_t *d_owner, const std::vector<int64_t> &owner)
 {
     DevMap &m = c->dm;
-    const size_t cells = (size_t)c->w * c->h, nys = ys.size();
+    const size_t cells = (size_t)c->w * c->h;
     const std::vector<float> angles = ad::sweep_angles();
-    const size_t n_ang = angles.size();
-    float *d_xs = nullptr, *d_ys = nullptr, *d_ang = nullptr, *d_dist = nullptr, *d_min = nullptr;
-    const size_t cols_per_tile = std::max<size_t>(1, std::min<size_t>(xs.size(), ((size_t)64 << 20) / std::max<size_t>(nys * n_ang * sizeof(float), 1)));
-    std::vector<float> dist(cols_per_tile * nys * n_ang), mind(xs.size() * nys);
-    int rc = upload(c, d_xs, xs);
+    if (angles.size() > HYAS_SWEEP_MAX)
+        return c->fail(HYAS_ERANGE, "more sweep angles than the kernel holds");
+    const size_t slack = 64;
+    float *d_ang = nullptr, *d_min = nullptr;
+    unsigned long long *d_total = nullptr, total = 0;
+    int rc = upload(c, d_ang, angles);
+    auto step = [&](hipError_t err, const char *what) {
+        if (rc == HYAS_OK && err != hipSuccess)
+            rc = hip_fail(c, err, what);
+        return rc == HYAS_OK;
+    };
     if (rc == HYAS_OK)
-        rc = upload(c, d_ys, ys);
+        step(hipMalloc((void **)&d_min, std::max<size_t>(cells, 1) * sizeof(float)), "hipMalloc(minimum distances)");
     if (rc == HYAS_OK)
-        rc = upload(c, d_ang, angles);
-    hipError_t e = hipSuccess;
-    if (rc == HYAS_OK && (e = hipMalloc((void **)&d_dist, dist.size() * sizeof(float))) != hipSuccess)
-        rc = hip_fail(c, e, "hipMalloc(sweep distances)");
-    if (rc == HYAS_OK && (e = hipMalloc((void **)&d_min, mind.size() * sizeof(float))) != hipSuccess)
-        rc = hip_fail(c, e, "hipMalloc(minimum distances)");
+        step(hipMalloc((void **)&d_total, sizeof(unsigned long long)), "hipMalloc(range total)");
+    if (rc == HYAS_OK)
+        step(hipMalloc((void **)&c->d_ad_off, (cells + 1) * sizeof(uint32_t) + slack), "hipMalloc(range offsets)");
+    if (rc == HYAS_OK)
+        step(hipMemsetAsync((char *)c->d_ad_off + (cells + 1) * sizeof(uint32_t), 0, slack, c->stream), "range offsets");
     if (rc == HYAS_OK)
     {
-        launch_min_distance(m, d_xs, (uint32_t)xs.size(), d_ys, (uint32_t)nys, d_min, c->stream);
-        e = hipGetLastError();
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(mind.data(), d_min, mind.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess)
-            rc = hip_fail(c, e, "minimum distances");
+        launch_adaptive_ranges(m, d_xs, d_ys, nys, d_owner, d_ang, (uint32_t)angles.size(), c->P.obstacle_detection_range, d_min, c->d_ad_off, nullptr,
+                               d_total, 0, c->stream);
+        step(hipGetLastError(), "angle range lengths");
     }
-    // min_distance_map_.emplace(key, ...): the owner's value (src/collisiondetection.cpp:1437)
+    if (rc == HYAS_OK)
+        step(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream), "angle range lengths");
+    if (rc == HYAS_OK)
+        step(hipStreamSynchronize(c->stream), "angle range lengths");
+    if (rc == HYAS_OK && total >= (1ull << 32) / 3)
+        rc = c->fail(HYAS_ERANGE, "too many angle ranges");
+    if (rc == HYAS_OK)
+        step(hipMalloc((void **)&c->d_ad_rng, std::max<size_t>((size_t)total, 1) * 3 * sizeof(float) + slack), "hipMalloc(angle ranges)");
+    if (rc == HYAS_OK)
+        step(hipMemsetAsync((char *)c->d_ad_rng + (size_t)total * 3 * sizeof(float), 0, slack + (total ? 0 : 3 * sizeof(float)), c->stream), "angle ranges");
+    if (rc == HYAS_OK)
+    {
+        launch_adaptive_ranges(m, d_xs, d_ys, nys, d_owner, d_ang, (uint32_t)angles.size(), c->P.obstacle_detection_range, d_min, c->d_ad_off,
+                               c->d_ad_rng, d_total, 1, c->stream);
+        step(hipGetLastError(), "angle ranges");
+    }
     c->ad_min_distance.assign(cells, 1000.f);
-    for (size_t key = 0; key < cells; ++key)
-        if (owner[key] >= 0)
-            c->ad_min_distance[key] = mind[(size_t)owner[key]];
-    std::vector<std::vector<ad::Range>> ranges(cells);
-    std::vector<std::vector<uint32_t>> keys_of_col(xs.size());
-    for (size_t key = 0; key < cells; ++key)
-        if (owner[key] >= 0)
-            keys_of_col[(size_t)owner[key] / nys].push_back((uint32_t)key);
-    for (size_t i0 = 0; rc == HYAS_OK && i0 < xs.size(); i0 += cols_per_tile)
-    {
-        const size_t ni = std::min(cols_per_tile, xs.size() - i0);
-        launch_sweep_distance(m, d_xs + i0, (uint32_t)ni, d_ys, (uint32_t)nys, d_ang, (uint32_t)n_ang, c->P.obstacle_detection_range, d_dist, c->stream);
-        e = hipGetLastError();
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(dist.data(), d_dist, ni * nys * n_ang * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess)
-        {
-            rc = hip_fail(c, e, "sweep distances");
-            break;
-        }
-        for (size_t i = i0; i < i0 + ni; ++i)
-            for (uint32_t key : keys_of_col[i])
-            {
-                const float *d = &dist[((size_t)owner[key] - i0 * nys) * n_ang];
-                ad::ranges_of_sweep(angles.data(), d, n_ang, c->ad_min_distance[key], c->P.obstacle_detection_range, ranges[key]);
-                ad::cut_to_circle(ranges[key]); // FindFreeAngleRangeAndObstacleAngleRange, the same for every node of the cell
-            }
-    }
-    for (float *p : {d_xs, d_ys, d_ang, d_dist, d_min})
+    c->ad_off.assign(cells + 1, 0);
+    c->ad_rng.assign((size_t)total * 3, 0.f);
+    if (rc == HYAS_OK)
+        step(hipMemcpyAsync(c->ad_min_distance.data(), d_min, cells * sizeof(float), hipMemcpyDeviceToHost, c->stream), "minimum distances");
+    if (rc == HYAS_OK)
+        step(hipMemcpyAsync(c->ad_off.data(), c->d_ad_off, (cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "angle range offsets");
+    if (rc == HYAS_OK && total)
+        step(hipMemcpyAsync(c->ad_rng.data(), c->d_ad_rng, (size_t)total * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "angle ranges");
+    if (rc == HYAS_OK)
+        step(hipStreamSynchronize(c->stream), "angle ranges");
+    for (void *p : {(void *)d_ang, (void *)d_min, (void *)d_total})
         if (p)
             (void)hipFree(p);
     if (rc != HYAS_OK)
@@ -973,20 +969,10 @@ static int build_adaptive_maps(hyas_ctx *c, const std::vector<float> &xs, const 
         }
     const float delta = 0.01f;
     c->ad_density.assign(cells, 0.f);
-    c->ad_off.assign(cells + 1, 0);
-    c->ad_rng.clear();
     for (size_t key = 0; key < cells; ++key)
-    {
-        c->ad_off[key] = (uint32_t)(c->ad_rng.size() / 3);
-        if (owner[key] < 0)
-            continue;
-        c->ad_density[key] = ((float)(c->cell_off[key + 1] - c->cell_off[key]) - min_density) / (max_density - min_density + delta);
-        for (const ad::Range &r : ranges[key])
-            c->ad_rng.push_back(r.dist), c->ad_rng.push_back(r.start), c->ad_rng.push_back(r.range);
-    }
-    c->ad_off[cells] = (uint32_t)(c->ad_rng.size() / 3);
-    if ((rc = upload(c, c->d_ad_off, c->ad_off)) != HYAS_OK || (rc = upload(c, c->d_ad_rng, c->ad_rng)) != HYAS_OK ||
-        (rc = upload(c, c->d_ad_density, c->ad_density)) != HYAS_OK)
+        if (owner[key] >= 0)
+            c->ad_density[key] = ((float)(c->cell_off[key + 1] - c->cell_off[key]) - min_density) / (max_density - min_density + delta);
+    if ((rc = upload(c, c->d_ad_density, c->ad_density)) != HYAS_OK)
         return rc;
     m.ad_off = c->d_ad_off, m.ad_rng = c->d_ad_rng, m.ad_density = c->d_ad_density;
     return HYAS_OK;
@@ -1090,13 +1076,24 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     // in_range_obstacle_map_.emplace(key, list): the first loop position that maps to a key keeps it
     // (src/collisiondetection.cpp:345); -1: no corner maps to the key
     std::vector<int64_t> owner(cells, -1);
+    float *d_xs = nullptr, *d_ys = nullptr; // the corner axes and the keys' owners on the device: the adaptive maps use them too
+    uint32_t *d_owner = nullptr;
+    struct FreeAxes
+    {
+        float *&xs, *&ys;
+        uint32_t *&owner;
+        ~FreeAxes()
+        {
+            for (void *p : {(void *)xs, (void *)ys, (void *)owner})
+                if (p)
+                    (void)hipFree(p);
+        }
+    } free_axes{d_xs, d_ys, d_owner};
     {
         // Lists on the GPU in two passes over (key, polygon): lengths, prefix sum, ids.  Nothing of size
         // cells x polygons is ever stored.
         const size_t slack = 64; // kernels fetch list entries in 16-byte blocks, one block ahead
         const size_t nq = c->quads.size();
-        float *d_xs = nullptr, *d_ys = nullptr;
-        uint32_t *d_owner = nullptr;
         unsigned long long *d_total = nullptr, total = 0;
         std::vector<uint32_t> owner_u(cells);
         rc = upload(c, d_xs, xs);
@@ -1171,7 +1168,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
             step(hipMemcpyAsync(owner_u.data(), d_owner, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream), "in-range lists");
         if (rc == HYAS_OK)
             step(hipStreamSynchronize(c->stream), "in-range lists");
-        for (void *p : {(void *)d_xs, (void *)d_ys, (void *)d_owner, (void *)d_total, (void *)bins.off, (void *)bins.idx})
+        for (void *p : {(void *)d_total, (void *)bins.off, (void *)bins.idx})
             if (p)
                 (void)hipFree(p);
         if (rc != HYAS_OK)
@@ -1182,7 +1179,7 @@ int hyas_set_costmap(hyas_ctx *c, const uint8_t *charmap, uint32_t w, uint32_t h
     mark("polygon bins and in-range lists, copies back");
     m.charmap = c->d_charmap, m.quads = c->d_quads, m.n_quads = (uint32_t)c->quads.size();
     m.cell_off = c->d_cell_off, m.cell_idx = c->d_cell_idx;
-    if (m.ad_mode != 0 && (rc = build_adaptive_maps(c, xs, ys, owner)) != HYAS_OK)
+    if (m.ad_mode != 0 && (rc = build_adaptive_maps(c, d_xs, d_ys, (uint32_t)ys.size(), d_owner, owner)) != HYAS_OK)
         return rc;
     mark("adaptive maps");
     {

@@ -641,53 +641,92 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(uint32_t *__restric
     }
 }
 
-// Adaptive step size / steering, map ingest.  For the cell corner (xs[i], ys[j]) and sweep angle a:
-// CollisionDetection::FindNoCollisionDistance (src/collisiondetection.cpp:973-1011), the nearest hit of the ray among
-// the corner's in-range obstacles, `radius` when none is hit: out[(i * nys + j) * n_ang + a].
-__global__ void __launch_bounds__(256) k_sweep_distance(DevMap m, const float *__restrict__ xs, uint32_t nxs, const float *__restrict__ ys, uint32_t nys,
-                                                        const float *__restrict__ angles, uint32_t n_ang, float radius, float *__restrict__ out)
+// Adaptive step size / steering, map ingest: the adaptive maps of every grid key in one kernel.  For the key's owner
+// corner: the minimum distance to its in-range obstacles, 1000 without any (CollisionDetection::SetMinDistanceMap,
+// src/collisiondetection.cpp:1403-1447); the sweep of HYAS_SWEEP_MAX rays at most, each the nearest hit among the
+// in-range obstacles or `radius` when none is hit (FindNoCollisionDistance, :973-1011; six rays per lane, into LDS);
+// then the run-length pass over the sweep and the cut to the circle (ad::ranges_of_sweep_each,
+// ad::cut_range_to_circle: SetDistanceAngleRangeMap and FindFreeAngleRangeAndObstacleAngleRange) on the wave's first
+// lane.  Nothing of size corners x rays leaves the chip.  One wave per key; FILL = false counts
+// (off[key] = number of ranges, min_distance[key]), FILL = true writes {label, start, width} behind off[key].
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_adaptive_ranges(DevMap m, const float *__restrict__ xs, const float *__restrict__ ys, uint32_t nys,
+                                                         const uint32_t *__restrict__ owner, const float *__restrict__ angles, uint32_t n_ang,
+                                                         float radius, float *__restrict__ min_distance, uint32_t *__restrict__ off,
+                                                         float *__restrict__ rng3)
 {
-    const size_t total = (size_t)nxs * nys * n_ang;
+    __shared__ float s_dist[4][HYAS_SWEEP_MAX];
+    __shared__ float s_ang[HYAS_SWEEP_MAX];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t cells = m.w * m.h;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    for (uint32_t a = threadIdx.x; a < n_ang; a += blockDim.x)
+        s_ang[a] = angles[a];
+    // (every wave of a workgroup makes the same number of trips: the barriers inside are the workgroup's)
+    for (size_t base = (size_t)blockIdx.x * 4; base < cells; base += (size_t)gridDim.x * 4)
     {
-        const uint32_t a = (uint32_t)(e % n_ang);
-        const size_t c = e / n_ang;
-        const F2 p = f2(xs[c / nys], ys[c % nys]);
-        const uint32_t key = grid_key(m, p.x, p.y);
-        float best = radius;
-        if (key < cells)
-            for (uint32_t k = m.cell_off[key]; k < m.cell_off[key + 1]; ++k)
-            {
-                const float t = ad::ray_distance(m.quads[m.cell_idx[k]], p, angles[a]);
-                if (t < 0)
-                    continue;
-                if (best > t)
-                    best = t;
-            }
-        out[e] = best;
-    }
-}
-// CollisionDetection::SetMinDistanceMap (src/collisiondetection.cpp:1403-1447): the nearest of the corner's in-range
-// obstacles, 1000 without any: out[i * nys + j].
-__global__ void __launch_bounds__(256) k_min_distance(DevMap m, const float *__restrict__ xs, uint32_t nxs, const float *__restrict__ ys, uint32_t nys,
-                                                      float *__restrict__ out)
-{
-    const size_t total = (size_t)nxs * nys;
-    const uint32_t cells = m.w * m.h;
-    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < total; c += (size_t)gridDim.x * blockDim.x)
-    {
-        const F2 p = f2(xs[c / nys], ys[c % nys]);
-        const uint32_t key = grid_key(m, p.x, p.y);
-        float best = 1000;
-        if (key < cells)
-            for (uint32_t k = m.cell_off[key]; k < m.cell_off[key + 1]; ++k)
+        const size_t key = base + wave;
+        const uint32_t pos = key < cells ? owner[key] : 0xFFFFFFFFu;
+        const bool have = pos != 0xFFFFFFFFu;
+        float md = 1000.f;
+        F2 p = f2(0.f, 0.f);
+        uint32_t b = 0, e = 0;
+        if (have)
+        {
+            p = f2(xs[pos / nys], ys[pos % nys]);
+            b = m.cell_off[key], e = m.cell_off[key + 1];
+            for (uint32_t k = b + lane; k < e; k += 64)
             {
                 const float d = dist_quad_point(m.quads[m.cell_idx[k]], p);
-                if (best > d)
-                    best = d;
+                if (md > d)
+                    md = d;
             }
-        out[c] = best;
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const float o = __shfl_xor(md, d, 64);
+                if (md > o)
+                    md = o;
+            }
+            for (uint32_t a = lane; a < n_ang; a += 64)
+            {
+                float best = radius;
+                for (uint32_t k = b; k < e; ++k)
+                {
+                    const float t = ad::ray_distance(m.quads[m.cell_idx[k]], p, s_ang[a]);
+                    if (t < 0)
+                        continue;
+                    if (best > t)
+                        best = t;
+                }
+                s_dist[wave][a] = best;
+            }
+        }
+        __syncthreads();
+        if (have && lane == 0)
+        {
+            uint32_t n = 0;
+            const uint32_t at = FILL ? off[key] : 0u;
+            ad::ranges_of_sweep_each([&](uint32_t i) { return s_ang[i]; }, [&](uint32_t i) { return s_dist[wave][i]; }, n_ang, md, radius,
+                                     [&](float label, float start, float width) {
+                                         ad::Range r{label, start, width};
+                                         if (!ad::cut_range_to_circle(r))
+                                             return;
+                                         if (FILL)
+                                         {
+                                             float *o = rng3 + 3 * (size_t)(at + n);
+                                             o[0] = r.dist, o[1] = r.start, o[2] = r.range;
+                                         }
+                                         ++n;
+                                     });
+            if (!FILL)
+                off[key] = n;
+        }
+        if (!FILL && lane == 0 && key < cells)
+        {
+            min_distance[key] = md;
+            if (!have)
+                off[key] = 0;
+        }
+        __syncthreads();
     }
 }
 
@@ -2412,19 +2451,20 @@ void launch_prune_lists(const Quad *quads, const uint32_t *cell_off, const uint1
         hipLaunchKernelGGL(k_prune_lists<true>, dim3(grid), dim3(256), 0, s, quads, cell_off, cell_idx, a, pose_off, pose_idx, seg_off, seg_idx);
 }
 
-void launch_sweep_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, const float *angles, uint32_t n_ang, float radius,
-                           float *out, hipStream_t s)
+void launch_adaptive_ranges(const DevMap &m, const float *xs, const float *ys, uint32_t nys, const uint32_t *owner, const float *angles, uint32_t n_ang,
+                            float radius, float *min_distance, uint32_t *off, float *rng3, unsigned long long *total, int pass, hipStream_t s)
 {
-    const size_t total = (size_t)nxs * nys * n_ang;
-    if (total)
-        hipLaunchKernelGGL(k_sweep_distance, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, m, xs, nxs, ys, nys, angles, n_ang, radius, out);
-}
-
-void launch_min_distance(const DevMap &m, const float *xs, uint32_t nxs, const float *ys, uint32_t nys, float *out, hipStream_t s)
-{
-    const size_t total = (size_t)nxs * nys;
-    if (total)
-        hipLaunchKernelGGL(k_min_distance, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, m, xs, nxs, ys, nys, out);
+    const uint32_t cells = m.w * m.h;
+    if (cells == 0)
+        return;
+    const int grid = grid_for(cells, 4, 256 * 32); // four waves (keys) per workgroup
+    if (pass == 0)
+    {
+        hipLaunchKernelGGL(k_adaptive_ranges<false>, dim3(grid), dim3(256), 0, s, m, xs, ys, nys, owner, angles, n_ang, radius, min_distance, off, rng3);
+        hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, off, (size_t)cells, total);
+    }
+    else
+        hipLaunchKernelGGL(k_adaptive_ranges<true>, dim3(grid), dim3(256), 0, s, m, xs, ys, nys, owner, angles, n_ang, radius, min_distance, off, rng3);
 }
 
 void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,

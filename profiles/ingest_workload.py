@@ -1,7 +1,10 @@
 """Map ingest timing: hyas_set_costmap (occupancy values, obstacle polygons, per-key in-range lists, pruned lists,
 footprint forms; no heuristic table) and hyas_set_grid (occupancy bit tiles) on maps of growing size.
 
-    python profiles/ingest_workload.py [--out FILE]        (HYAS_LIB=<other libhyas.so> times another build)
+    python profiles/ingest_workload.py [--adaptive] [--out FILE]     (HYAS_LIB=<other libhyas.so> times another build)
+
+--adaptive times the same maps with adaptive_steering_angle_and_step_size = 1, where hyas_set_costmap also builds the
+adaptive maps (per key: minimum obstacle distance, free and obstacle angle ranges, obstacle density).
 
 Prints one JSON line: per map the cells, obstacle polygons, list entries and the median seconds of five calls.
 """
@@ -40,8 +43,10 @@ def median_seconds(fn, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out")
+    ap.add_argument("--adaptive", action="store_true")
     a = ap.parse_args()
-    h = Hyas(hot_path_params(position_resolution=1), device=0)
+    switches = dict(adaptive_steering_angle_and_step_size=1) if a.adaptive else {}
+    h = Hyas(hot_path_params(position_resolution=1, **switches), device=0)
     rows = []
     maps = [("map_maze 50x50", load_map("map_maze")), ("map_large 180x60", load_map("map_large")),
             ("random 400x300, 4% occupied", random_costmap(400, 300, 1, 0.04)),
@@ -54,7 +59,7 @@ def main():
                      "cell_polygon_pairs": int(m.size) * int(n_quads), "set_costmap_s": s})
     g = random_costmap(4096, 4096, 1, 0.10)
     rows.append({"map": "grid 4096x4096 (hyas_set_grid)", "cells": int(g.size), "set_grid_s": median_seconds(lambda: h.set_grid(g))})
-    line = json.dumps({"workload": "map ingest", "rows": rows})
+    line = json.dumps({"workload": "map ingest, adaptive maps included" if a.adaptive else "map ingest", "rows": rows})
     print(line)
     if a.out:
         Path(a.out).write_text(line + "\n")
