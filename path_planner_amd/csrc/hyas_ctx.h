@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "hyas_hugepool.h"
 #include "hyas_kernels.h"
 
 #define HYAS_MAX_GROUPS 16

@@ -757,6 +757,8 @@ void hyas_destroy(hyas_ctx *c)
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
+    // the searches' host memory goes back to the system, unless another context still holds results or is planning
+    (void)HugePool::instance().trim();
 }
 
 const char *hyas_last_error(const hyas_ctx *c) { return c ? c->err.c_str() : "null context"; }

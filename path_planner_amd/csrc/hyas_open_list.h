@@ -5,6 +5,8 @@
 #include <cstring>
 #include <vector>
 
+#include "hyas_hugepool.h"
+
 namespace hyas
 {
 
@@ -31,7 +33,7 @@ struct OpenList
     };
     HeapItem hot[HOT]; // hot[nh - 1] is the best entry, hot[0] the worst of the array
     int nh = 0;
-    std::vector<HeapItem> cold;
+    HVec<HeapItem> cold; // (storage from the huge-page pool: every query has one, touched out of order)
     bool empty() const { return nh == 0; } // (the array is refilled whenever it runs dry)
     size_t size() const { return (size_t)nh + cold.size(); }
     const HeapItem &top() const { return hot[nh - 1]; }

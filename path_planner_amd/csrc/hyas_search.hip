@@ -53,7 +53,7 @@ struct CellMap
         float g;
         uint8_t open, closed;
     };
-    std::vector<Slot> slots;
+    HVec<Slot> slots;
     size_t used = 0;
     void init(size_t cap)
     {
@@ -92,7 +92,7 @@ struct CellMap
     }
     void grow()
     {
-        std::vector<Slot> old;
+        HVec<Slot> old;
         old.swap(slots);
         slots.assign(old.size() * 2, Slot{-1, 999.f, 0, 0});
         used = 0;
@@ -108,11 +108,11 @@ struct Query
     hyas_goal goal;
     SNode start;
     uint32_t dist_start_goal_bits = 0; // bits of the float GetDistance(start, goal), for the adaptive steering selection
-    std::vector<SNode> arena;
+    HVec<SNode> arena;
     OpenList open;
     uint32_t seq = 0;
     CellMap cells;
-    std::vector<int32_t> dup_head; // spatial hash over the open list
+    HVec<int32_t> dup_head; // spatial hash over the open list
     int iterations = 0, counter = 0, N = 0;
     int cur = -1, cur_idx = 0; // node being expanded this round
     // nodes handed to the kernel this round: spec[0] = cur, the others are the open list's next best entries,
@@ -138,7 +138,7 @@ struct Query
     int shot_from = -1; // >= 0: finished through an analytic shot from this node
     int end_node = -1, end_status = 0; // >= 0: finished at this node by the goal test or the iteration limit
     hyas_result res{};
-    std::vector<int32_t> expanded;
+    std::vector<int32_t> expanded; // (plain pages: with these lists in the huge-page pool as well most of its gain was lost, measured)
     std::vector<float> path;
 };
 
@@ -964,7 +964,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     {
         size_t base = 0, cn = 0;
         int buf = 0, rc = HYAS_OK;
-        std::vector<Query> Q;
+        HVec<Query> Q;
         double t_gpu = 0, t_all = 0;
     };
     auto prepare = [&](Prep &P, bool overlapped) -> int {
@@ -974,7 +974,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
         hipStream_t st = c->prep_stream;
         P.Q.clear();
         P.Q.resize(cn);
-        std::vector<Query> &Q = P.Q;
+        HVec<Query> &Q = P.Q;
         hyas_goal *h_goal = (hyas_goal *)(hs + o.goal);
         // makePlan pre-checks (src/hybrid_a_star_planner.cpp:126-155): start and goal poses through the pose test;
         // the start node's curve cost (:63) from the heuristic table: both on the GPU, in one trip
@@ -1083,7 +1083,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
     {
         const auto wall0 = std::chrono::steady_clock::now();
         const size_t cn = cur.cn, base = cur.base;
-        std::vector<Query> &Q = cur.Q;
+        HVec<Query> &Q = cur.Q;
         const size_t o_goal = po[cur.buf].goal;
         const float *const d_twod_cur = c->d_twod + (size_t)cur.buf * twod_stride;
         // the next chunk's set-up runs on a thread of its own (own stream, own buffers) while this chunk's rounds run
@@ -1177,8 +1177,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 G[gi].live.push_back((uint32_t)i);
         }
         std::vector<uint8_t> wants(cn);
-        std::vector<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
-        std::vector<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
+        HVec<StepIn> stage(cn * KS); // next round's input of every query, filled by the worker that popped it
+        HVec<uint32_t> slot0(cn);    // where a query's nodes lie in its group's launch
         const bool P_analytic = c->P.analytical_expansion != 0;
         std::atomic<uint64_t> miss_child{0}, miss_other{0};
         // what every worker counts for itself (summed after the rounds): answers used ahead of time, and with HYAS_TRACE

@@ -507,3 +507,68 @@ extern "C" int hg_cut_to_circle(const float *in3, int n, float *out3)
         out3[3 * i] = v[i].dist, out3[3 * i + 1] = v[i].start, out3[3 * i + 2] = v[i].range;
     return (int)v.size();
 }
+
+// The huge-page pool behind the searches' host state: blocks of many sizes from several threads' worth of requests are
+// distinct, 64-byte aligned, at least as large as asked and keep what is written into them; a freed block comes back for
+// the next request of its size; trim() releases nothing while a block is in use and every region once none is.
+// Returns the number of violations.
+extern "C" long hg_hugepool_violations(const uint32_t *sizes, int n)
+{
+    HugePool &pool = HugePool::instance();
+    long bad = 0;
+    std::vector<std::pair<unsigned char *, size_t>> blocks;
+    for (int i = 0; i < n; ++i)
+    {
+        const size_t bytes = sizes[i];
+        size_t rounded = 0;
+        const int cls = HugePool::class_of(bytes, rounded);
+        if (bytes <= HugePool::BIGGEST && (rounded < bytes || cls < 0 || cls >= HugePool::N_CLASSES || rounded > bytes + bytes / 4 + 64))
+            ++bad;
+        unsigned char *p = (unsigned char *)pool.allocate(bytes);
+        if (((uintptr_t)p & 63u) != 0)
+            ++bad;
+        std::memset(p, i & 0xFF, bytes);
+        blocks.emplace_back(p, bytes);
+    }
+    // no two blocks overlap, and every block still holds its own byte
+    std::vector<std::pair<uintptr_t, uintptr_t>> spans;
+    for (int i = 0; i < n; ++i)
+    {
+        spans.emplace_back((uintptr_t)blocks[i].first, (uintptr_t)blocks[i].first + blocks[i].second);
+        for (size_t k = 0; k < blocks[i].second; k += 509)
+            if (blocks[i].first[k] != (unsigned char)(i & 0xFF))
+                ++bad;
+        if (blocks[i].second && blocks[i].first[blocks[i].second - 1] != (unsigned char)(i & 0xFF))
+            ++bad;
+    }
+    std::sort(spans.begin(), spans.end());
+    for (size_t i = 1; i < spans.size(); ++i)
+        if (spans[i].first < spans[i - 1].second)
+            ++bad;
+    if (n > 0 && pool.trim() != 0) // blocks in use: nothing may be released
+        ++bad;
+    // a freed block is the next one handed out for its size
+    if (n > 0)
+    {
+        unsigned char *p0 = blocks[0].first;
+        const size_t b0 = blocks[0].second;
+        pool.deallocate(p0, b0);
+        unsigned char *again = (unsigned char *)pool.allocate(b0);
+        if (b0 <= HugePool::BIGGEST && again != p0)
+            ++bad;
+        blocks[0].first = again;
+    }
+    for (auto &b : blocks)
+        pool.deallocate(b.first, b.second);
+    const size_t mapped = pool.mapped_bytes();
+    if (pool.trim() != mapped + (mapped / HugePool::REGION) * HugePool::HUGE_PAGE || pool.mapped_bytes() != 0)
+        ++bad;
+    // and the pool works again afterwards, through the container alias too
+    HVec<int> v;
+    for (int i = 0; i < 100000; ++i)
+        v.push_back(i);
+    for (int i = 0; i < 100000; i += 997)
+        if (v[i] != i)
+            ++bad;
+    return bad;
+}

@@ -25,7 +25,7 @@ def host_geom():
     deps = [src, ROOT / "path_planner_amd/csrc/hyas_dev.h", ROOT / "path_planner_amd/csrc/hyas_prune.h", ROOT / "include/hyas_math.h",
             ROOT / "path_planner_amd/csrc/hyas_rs.h", ROOT / "path_planner_amd/csrc/hyas_flood.h",
             ROOT / "path_planner_amd/csrc/hyas_bezier.h", ROOT / "path_planner_amd/csrc/hyas_adaptive.h",
-            ROOT / "path_planner_amd/csrc/hyas_open_list.h"]
+            ROOT / "path_planner_amd/csrc/hyas_open_list.h", ROOT / "path_planner_amd/csrc/hyas_hugepool.h"]
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-D__host__=", "-D__device__=",
                         "-D__forceinline__=inline", f"-I{ROOT / 'include'}", "-o", str(so), str(src)], check=True)
@@ -133,6 +133,16 @@ def test_open_list_pops_in_cost_then_push_order(host_geom):
         u = rng.random(n)
         op = np.ascontiguousarray(np.where(u < p_pop, 1, np.where(u < p_pop + 0.05, 2, 0)).astype(np.uint8))
         assert host_geom.hg_open_list_mismatches(f.ctypes.data_as(C.c_void_p), op.ctypes.data_as(C.c_void_p), n) == 0
+
+
+def test_huge_page_pool_hands_out_sound_blocks(host_geom):
+    """The pool behind the searches' host state (open lists, cell maps, arenas): sizes from one byte to beyond the largest
+    pooled block; blocks distinct, aligned, intact, reused after a free, and all regions released by trim() at the end."""
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([np.arange(1, 70), 2 ** np.arange(6, 25), 2 ** np.arange(6, 24) + 1, 5 * 2 ** np.arange(8, 20),
+                            rng.integers(1, 300000, 3000), [(16 << 20) + 1, 40 << 20]]).astype(np.uint32)
+    host_geom.hg_hugepool_violations.restype = C.c_long
+    assert host_geom.hg_hugepool_violations(np.ascontiguousarray(sizes).ctypes.data_as(C.c_void_p), len(sizes)) == 0
 
 
 def test_flood_queue_pops_like_the_reference_priority_queue(host_geom):
