@@ -24,8 +24,8 @@ class HugePool
   public:
     static HugePool &instance()
     {
-        static HugePool pool;
-        return pool;
+        static HugePool *pool = new HugePool; // never destroyed: contexts may be torn down after the static destructors ran
+        return *pool;
     }
     void *allocate(size_t bytes)
     {
