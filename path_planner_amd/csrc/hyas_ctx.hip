@@ -714,13 +714,21 @@ void hyas_destroy(hyas_ctx *c)
 {
     if (!c)
         return;
+    const bool trace = std::getenv("HYAS_TRACE") != nullptr; // where a teardown that does not come back stands
+    auto mark = [trace](const char *what) {
+        if (trace)
+            fprintf(stderr, "hyas destroy: %s\n", what), fflush(stderr);
+    };
+    mark("begin");
     (void)hipSetDevice(c->device);
     free_search_pools(c);
+    mark("worker threads joined");
     for (int g = 0; g < HYAS_MAX_GROUPS; ++g) // round_stream[0] is c->stream
         if (c->round_stream[g])
             (void)hipStreamSynchronize(c->round_stream[g]);
     if (c->prep_stream)
         (void)hipStreamSynchronize(c->prep_stream);
+    mark("streams drained");
     free_map(c);
     if (c->d_flood_ws)
         (void)hipFree(c->d_flood_ws);
@@ -756,9 +764,11 @@ void hyas_destroy(hyas_ctx *c)
         (void)hipStreamDestroy(c->prep_stream);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
+    mark("device memory, events and streams released");
     delete c;
     // the searches' host memory goes back to the system, unless another context still holds results or is planning
     (void)HugePool::instance().trim();
+    mark("done");
 }
 
 const char *hyas_last_error(const hyas_ctx *c) { return c ? c->err.c_str() : "null context"; }

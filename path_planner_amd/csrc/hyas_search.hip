@@ -162,6 +162,7 @@ struct ConsumeProbe
     uint64_t dup = 0, cell = 0, push = 0, chain = 0, heads = 0, succ = 0, pushed = 0;
     uint64_t drop_closed = 0, drop_worse = 0, drop_tie = 0, drop_dup = 0; // successors dropped, by the test that dropped them
     uint64_t waited = 0, waits = 0; // cycles spent waiting for answer units that had not arrived, and how often
+    uint64_t waited_shot = 0, waits_shot = 0; // ... of which for the shot's answer (the rest: successor count and records)
 };
 static thread_local ConsumeProbe t_probe;
 
@@ -1211,7 +1212,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 (void)hipGetLastError();
             }
         };
-        auto unit = [&](const char *p, uint32_t tag, int shift, uint32_t w[4]) -> bool {
+        auto unit = [&](const char *p, uint32_t tag, int shift, uint32_t w[4], bool is_shot = false) -> bool {
             uint64_t wait0 = 0;
             for (uint64_t spins = 0;; ++spins)
             {
@@ -1219,7 +1220,12 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                 if (((w[3] >> shift) & ROUND_TAG_MASK) == tag)
                 {
                     if (spins && trace_on)
-                        t_probe.waited += __builtin_ia32_rdtsc() - wait0, t_probe.waits += 1;
+                    {
+                        const uint64_t dt = __builtin_ia32_rdtsc() - wait0;
+                        t_probe.waited += dt, t_probe.waits += 1;
+                        if (is_shot)
+                            t_probe.waited_shot += dt, t_probe.waits_shot += 1;
+                    }
                     return true;
                 }
                 if (!spins && trace_on)
@@ -1382,7 +1388,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                             float shot_len = 0;
                             if (q.shoot)
                             {
-                                if (!unit(blk, read_tag, 0, w))
+                                if (!unit(blk, read_tag, 0, w, true))
                                     return;
                                 shot_ok = (uint8_t)w[1];
                                 std::memcpy(&shot_len, &w[0], 4);
@@ -1785,6 +1791,7 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
             sum.probe.heads += tl.probe.heads, sum.probe.succ += tl.probe.succ, sum.probe.pushed += tl.probe.pushed;
             sum.probe.drop_closed += tl.probe.drop_closed, sum.probe.drop_worse += tl.probe.drop_worse, sum.probe.drop_tie += tl.probe.drop_tie;
             sum.probe.drop_dup += tl.probe.drop_dup, sum.probe.waited += tl.probe.waited, sum.probe.waits += tl.probe.waits;
+            sum.probe.waited_shot += tl.probe.waited_shot, sum.probe.waits_shot += tl.probe.waits_shot;
         }
         double t_host = 0, t_launch = 0;
         for (int gi = 0; gi < ng; ++gi)
@@ -1829,7 +1836,8 @@ int plan_batch_impl(hyas_ctx *c, const float *starts, const float *goals, size_t
                     (double)sum.probe.succ, (double)sum.probe.dup, (double)sum.probe.heads, (double)sum.probe.chain, (double)sum.probe.cell,
                     (double)sum.probe.pushed, (double)sum.probe.push);
         if (trace_on)
-            fprintf(stderr, "hyas answers waited for: %.3e times, %.3e cycles in all\n", (double)sum.probe.waits, (double)sum.probe.waited);
+            fprintf(stderr, "hyas answers waited for: %.3e times, %.3e cycles in all; of which the shot's answer %.3e times, %.3e cycles\n", (double)sum.probe.waits,
+                    (double)sum.probe.waited, (double)sum.probe.waits_shot, (double)sum.probe.waited_shot);
         if (trace_on)
             fprintf(stderr, "hyas successors dropped: cell closed %.3e, cell open with a cost not worse %.3e, same cell beyond the tie breaker %.3e, "
                             "duplicate of an open-list entry %.3e\n",
