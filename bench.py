@@ -376,7 +376,17 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    _KEEP_ALIVE.append(ctx)  # (no context teardown between the line and the end of the process, see below)
+
+
+_KEEP_ALIVE = []
 
 
 if __name__ == "__main__":
     main()
+    # The line is out and every rank has passed the last barrier: end here, without the interpreter's teardown.  The
+    # process holds two HIP runtimes (torch's own and the one the library links), and one run in several hundred did
+    # not come back from tearing them down after its line was printed.
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
