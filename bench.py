@@ -373,20 +373,18 @@ def main():
             "queries_large_strong": curve,
         }
         print(json.dumps(line))
+    # The line is out.  The process holds two HIP runtimes (torch's own and the one the library links), and one run in
+    # several hundred did not come back from tearing things down after its line: if the rest of the process (the last
+    # barrier, the context's teardown, the interpreter's) takes longer than two minutes, the alarm's default action ends it.
+    sys.stdout.flush()
+    sys.stderr.flush()
+    import signal
+
+    signal.alarm(120)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    _KEEP_ALIVE.append(ctx)  # (no context teardown between the line and the end of the process, see below)
-
-
-_KEEP_ALIVE = []
 
 
 if __name__ == "__main__":
     main()
-    # The line is out and every rank has passed the last barrier: end here, without the interpreter's teardown.  The
-    # process holds two HIP runtimes (torch's own and the one the library links), and one run in several hundred did
-    # not come back from tearing them down after its line was printed.
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
