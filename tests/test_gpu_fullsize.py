@@ -214,6 +214,50 @@ def test_search_schedule_does_not_change_answers(maze_ctx, monkeypatch):
             assert np.array_equal(h.path(i), keep[i][0]) and np.array_equal(h.expanded(i), keep[i][1]), (env, i)
 
 
+def test_two_contexts_plan_at_once_and_one_is_destroyed_meanwhile(maze_ctx):
+    """Two contexts of one process planning at the same time from two host threads (one GPU each in a real process; both
+    on this GPU here) share nothing but the pool behind the searches' host memory: both give the answers of a call on its
+    own, also when a third context is created, used and destroyed while they are planning (its teardown asks the pool to
+    release its regions, which it must refuse while blocks are in use)."""
+    import threading
+
+    mp = orc.load_map("map_maze")
+    S, G = make_queries(maze_ctx.collision, 256, 99, 50, 50)
+    want = maze_ctx.plan_batch(S, G)
+    want_exp = [maze_ctx.expanded(i) for i in range(0, 256, 5)]
+    ctxs = []
+    for _ in range(2):
+        h = Hyas(hot_path_params())
+        h.set_costmap(mp, build_table=True)
+        ctxs.append(h)
+    got, errors = [None, None], []
+
+    def plan(t):
+        try:
+            for _ in range(3):
+                got[t] = ctxs[t].plan_batch(S, G)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=plan, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for _ in range(3):
+        h3 = Hyas(hot_path_params())
+        h3.set_costmap(mp, build_table=True)
+        r3 = h3.plan_batch(S[:8], G[:8])
+        assert r3.tobytes() == want[:8].tobytes()
+        h3.close()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    for t in range(2):
+        assert got[t].tobytes() == want.tobytes()
+        for k, i in enumerate(range(0, 256, 5)):
+            assert np.array_equal(ctxs[t].expanded(i), want_exp[k])
+        ctxs[t].close()
+
+
 def test_round_timing_switch(maze_ctx):
     """hyas_set_round_timing: off (the default) the search rounds carry no timing events and report no kernel time; on,
     every second launch of a query group is timed and the sum scaled to all launches; the answers are the same."""
