@@ -914,8 +914,12 @@ static int build_adaptive_maps(hyas_ctx *c, const float *d_xs, const float *d_ys
     if (angles.size() > HYAS_SWEEP_MAX)
         return c->fail(HYAS_ERANGE, "more sweep angles than the kernel holds");
     const size_t slack = 64;
-    float *d_ang = nullptr, *d_min = nullptr;
+    float *d_ang = nullptr, *d_min = nullptr, *d_kept = nullptr;
     unsigned long long *d_total = nullptr, total = 0;
+    // the first ranges of every key are kept between the two passes (a cell has three or four on average, rarely more
+    // than eight), unless the map is so large that the room for them would be
+    const uint32_t keep = std::getenv("HYAS_ADAPTIVE_KEEP") ? (uint32_t)std::max(0, std::min(21, std::atoi(std::getenv("HYAS_ADAPTIVE_KEEP")))) : 8u; // (test knob)
+    const size_t kept_bytes = cells * keep * 3 * sizeof(float);
     int rc = upload(c, d_ang, angles);
     auto step = [&](hipError_t err, const char *what) {
         if (rc == HYAS_OK && err != hipSuccess)
@@ -926,6 +930,11 @@ static int build_adaptive_maps(hyas_ctx *c, const float *d_xs, const float *d_ys
         step(hipMalloc((void **)&d_min, std::max<size_t>(cells, 1) * sizeof(float)), "hipMalloc(minimum distances)");
     if (rc == HYAS_OK)
         step(hipMalloc((void **)&d_total, sizeof(unsigned long long)), "hipMalloc(range total)");
+    if (rc == HYAS_OK && kept_bytes != 0 && kept_bytes <= ((size_t)512 << 20) && hipMalloc((void **)&d_kept, kept_bytes) != hipSuccess)
+    {
+        (void)hipGetLastError(); // (without the room both passes sweep)
+        d_kept = nullptr;
+    }
     if (rc == HYAS_OK)
         step(hipMalloc((void **)&c->d_ad_off, (cells + 1) * sizeof(uint32_t) + slack), "hipMalloc(range offsets)");
     if (rc == HYAS_OK)
@@ -933,7 +942,7 @@ static int build_adaptive_maps(hyas_ctx *c, const float *d_xs, const float *d_ys
     if (rc == HYAS_OK)
     {
         launch_adaptive_ranges(m, d_xs, d_ys, nys, d_owner, d_ang, (uint32_t)angles.size(), c->P.obstacle_detection_range, d_min, c->d_ad_off, nullptr,
-                               d_total, 0, c->stream);
+                               d_kept, keep, d_total, 0, c->stream);
         step(hipGetLastError(), "angle range lengths");
     }
     if (rc == HYAS_OK)
@@ -949,7 +958,7 @@ static int build_adaptive_maps(hyas_ctx *c, const float *d_xs, const float *d_ys
     if (rc == HYAS_OK)
     {
         launch_adaptive_ranges(m, d_xs, d_ys, nys, d_owner, d_ang, (uint32_t)angles.size(), c->P.obstacle_detection_range, d_min, c->d_ad_off,
-                               c->d_ad_rng, d_total, 1, c->stream);
+                               c->d_ad_rng, d_kept, keep, d_total, 1, c->stream);
         step(hipGetLastError(), "angle ranges");
     }
     c->ad_min_distance.assign(cells, 1000.f);
@@ -963,7 +972,7 @@ static int build_adaptive_maps(hyas_ctx *c, const float *d_xs, const float *d_ys
         step(hipMemcpyAsync(c->ad_rng.data(), c->d_ad_rng, (size_t)total * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "angle ranges");
     if (rc == HYAS_OK)
         step(hipStreamSynchronize(c->stream), "angle ranges");
-    for (void *p : {(void *)d_ang, (void *)d_min, (void *)d_total})
+    for (void *p : {(void *)d_ang, (void *)d_min, (void *)d_total, (void *)d_kept})
         if (p)
             (void)hipFree(p);
     if (rc != HYAS_OK)

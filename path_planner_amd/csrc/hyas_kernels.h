@@ -90,10 +90,12 @@ void launch_prune_lists(const Quad *quads, const uint32_t *cell_off, const uint1
                         uint32_t *seg_off, uint16_t *seg_idx, unsigned long long *totals2, int pass, hipStream_t s);
 // Adaptive maps of every grid key (w*h keys; owner[key] = 0xFFFFFFFF: no corner maps to it): pass 0 leaves
 // min_distance[key], the offsets of the keys' range lists in off[0..w*h] and their total in *total; pass 1 writes the
-// ranges {label, start, width} into rng3.  n_ang <= HYAS_SWEEP_MAX.
+// ranges {label, start, width} into rng3.  n_ang <= HYAS_SWEEP_MAX.  kept (optional, w*h*keep*3 floats, keep <= 21): where
+// pass 0 leaves every key's first `keep` ranges, so that pass 1 only sweeps again for the keys that have more.
 #define HYAS_SWEEP_MAX 368u
 void launch_adaptive_ranges(const DevMap &m, const float *xs, const float *ys, uint32_t nys, const uint32_t *owner, const float *angles, uint32_t n_ang,
-                            float radius, float *min_distance, uint32_t *off, float *rng3, unsigned long long *total, int pass, hipStream_t s);
+                            float radius, float *min_distance, uint32_t *off, float *rng3, float *kept, uint32_t keep, unsigned long long *total, int pass,
+                            hipStream_t s);
 void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,
                      float *out, hipStream_t s);
 void launch_table_dubins(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, float rho,

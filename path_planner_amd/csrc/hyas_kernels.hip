@@ -649,11 +649,13 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(uint32_t *__restric
 // ad::cut_range_to_circle: SetDistanceAngleRangeMap and FindFreeAngleRangeAndObstacleAngleRange) on the wave's first
 // lane.  Nothing of size corners x rays leaves the chip.  One wave per key; FILL = false counts
 // (off[key] = number of ranges, min_distance[key]), FILL = true writes {label, start, width} behind off[key].
+// kept (optional): room for `keep` ranges per key.  The counting pass leaves a key's first `keep` ranges there, and the
+// filling pass copies them for every key that has no more than that instead of sweeping again.
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_adaptive_ranges(DevMap m, const float *__restrict__ xs, const float *__restrict__ ys, uint32_t nys,
                                                          const uint32_t *__restrict__ owner, const float *__restrict__ angles, uint32_t n_ang,
                                                          float radius, float *__restrict__ min_distance, uint32_t *__restrict__ off,
-                                                         float *__restrict__ rng3)
+                                                         float *__restrict__ rng3, float *__restrict__ kept, uint32_t keep)
 {
     __shared__ float s_dist[4][HYAS_SWEEP_MAX];
     __shared__ float s_ang[HYAS_SWEEP_MAX];
@@ -670,7 +672,11 @@ __global__ void __launch_bounds__(256) k_adaptive_ranges(DevMap m, const float *
         float md = 1000.f;
         F2 p = f2(0.f, 0.f);
         uint32_t b = 0, e = 0;
-        if (have)
+        const uint32_t n_known = FILL && have && kept ? off[key + 1] - off[key] : 0xFFFFFFFFu;
+        const bool copy = n_known <= keep; // (uniform across the wave)
+        if (copy && lane < 3 * n_known)
+            rng3[3 * (size_t)off[key] + lane] = kept[(size_t)key * keep * 3 + lane];
+        if (have && !copy)
         {
             p = f2(xs[pos / nys], ys[pos % nys]);
             b = m.cell_off[key], e = m.cell_off[key + 1];
@@ -701,7 +707,7 @@ __global__ void __launch_bounds__(256) k_adaptive_ranges(DevMap m, const float *
             }
         }
         __syncthreads();
-        if (have && lane == 0)
+        if (have && !copy && lane == 0)
         {
             uint32_t n = 0;
             const uint32_t at = FILL ? off[key] : 0u;
@@ -710,9 +716,9 @@ __global__ void __launch_bounds__(256) k_adaptive_ranges(DevMap m, const float *
                                          ad::Range r{label, start, width};
                                          if (!ad::cut_range_to_circle(r))
                                              return;
-                                         if (FILL)
+                                         if (FILL || (kept && n < keep))
                                          {
-                                             float *o = rng3 + 3 * (size_t)(at + n);
+                                             float *o = FILL ? rng3 + 3 * (size_t)(at + n) : kept + 3 * ((size_t)key * keep + n);
                                              o[0] = r.dist, o[1] = r.start, o[2] = r.range;
                                          }
                                          ++n;
@@ -2452,19 +2458,22 @@ void launch_prune_lists(const Quad *quads, const uint32_t *cell_off, const uint1
 }
 
 void launch_adaptive_ranges(const DevMap &m, const float *xs, const float *ys, uint32_t nys, const uint32_t *owner, const float *angles, uint32_t n_ang,
-                            float radius, float *min_distance, uint32_t *off, float *rng3, unsigned long long *total, int pass, hipStream_t s)
+                            float radius, float *min_distance, uint32_t *off, float *rng3, float *kept, uint32_t keep, unsigned long long *total, int pass,
+                            hipStream_t s)
 {
+    if (!kept || keep > 21) // (a wave copies a key's kept ranges with one lane per float)
+        kept = nullptr, keep = 0;
     const uint32_t cells = m.w * m.h;
     if (cells == 0)
         return;
     const int grid = grid_for(cells, 4, 256 * 32); // four waves (keys) per workgroup
     if (pass == 0)
     {
-        hipLaunchKernelGGL(k_adaptive_ranges<false>, dim3(grid), dim3(256), 0, s, m, xs, ys, nys, owner, angles, n_ang, radius, min_distance, off, rng3);
+        hipLaunchKernelGGL(k_adaptive_ranges<false>, dim3(grid), dim3(256), 0, s, m, xs, ys, nys, owner, angles, n_ang, radius, min_distance, off, rng3, kept, keep);
         hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, s, off, (size_t)cells, total);
     }
     else
-        hipLaunchKernelGGL(k_adaptive_ranges<true>, dim3(grid), dim3(256), 0, s, m, xs, ys, nys, owner, angles, n_ang, radius, min_distance, off, rng3);
+        hipLaunchKernelGGL(k_adaptive_ranges<true>, dim3(grid), dim3(256), 0, s, m, xs, ys, nys, owner, angles, n_ang, radius, min_distance, off, rng3, kept, keep);
 }
 
 void launch_table_rs(const float *xs, uint32_t nx, const float *ys, uint32_t ny, const float *ts, uint32_t k0, uint32_t k1, double rho,

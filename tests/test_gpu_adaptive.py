@@ -45,6 +45,26 @@ def test_adaptive_maps(oracle_built, name, res, ox, oy):
     assert seen >= p.W * p.H - 1
 
 
+@pytest.mark.parametrize("keep", ["0", "2", "21"])
+def test_adaptive_maps_whatever_the_passes_keep(oracle_built, monkeypatch, keep):
+    """The map build counts the ranges of every key, then fills them in; the counting pass keeps each key's first few
+    ranges so that the filling pass need not sweep again (HYAS_ADAPTIVE_KEEP, default 8).  None kept, fewer than most
+    cells have, and more than any cell has: the maps are the oracle's."""
+    monkeypatch.setenv("HYAS_ADAPTIVE_KEEP", keep)
+    p = Pair("map_maze", position_resolution=1, **COMBINED)
+    most = 0
+    for key in range(p.W * p.H):
+        want = p.o.adaptive_cell(key, cut=True)
+        md, de, rng = p.h.adaptive_cell(key)
+        if want is None:
+            assert len(rng) == 0 and de == 0
+            continue
+        most = max(most, len(rng))
+        assert np.float32(want[0]).view(np.uint32) == np.float32(md).view(np.uint32), key
+        assert want[2].tobytes() == rng.tobytes(), (key, want[2], rng)
+    assert most > 8  # the default keeps eight: the maze has cells beyond that, so test_adaptive_maps covers both ways
+
+
 def test_adaptive_modes_with_map_boundary_obstacle(oracle_built):
     """The boundary rectangles of map_boundary_obstacle = 1 take part in the sweeps and the density like any obstacle."""
     p = Pair("map_parking", position_resolution=1, max_iterations=300, map_boundary_obstacle=1, **COMBINED)
