@@ -88,6 +88,60 @@ def test_reeds_shepp_sampling_reaches_goal(ora):
         assert math.hypot(pts[-1, 0] - b[0], pts[-1, 1] - b[1]) <= 0.1 + 1e-6
 
 
+# The word table of src/ReedsShepp.cpp:506-525 (OMPL's), as data: 'L', 'R', 'S' per segment
+RS_WORDS = ["LRL", "RLR", "LRLR", "RLRL", "LRSL", "RLSR", "LSRL", "RSLR", "LRSR", "RLSL", "RSRL", "LSLR", "LSR", "RSL", "LSL", "RSR",
+            "LRSLR", "RLSRL"]
+
+
+def _drive(word, lengths):
+    """End pose of a car (unit turning radius) that starts at (0, 0, 0) and drives the word's segments by their signed
+    lengths: exact arcs and lines, independent of the solver's own interpolation."""
+    x = y = th = 0.0
+    for kind, v in zip(word, lengths):
+        if kind == "S":
+            x, y = x + v * math.cos(th), y + v * math.sin(th)
+        elif kind == "L":
+            x, y, th = x + math.sin(th + v) - math.sin(th), y - math.cos(th + v) + math.cos(th), th + v
+        else:
+            x, y, th = x - math.sin(th - v) + math.sin(th), y + math.cos(th - v) - math.cos(th), th - v
+    return x, y, th
+
+
+def test_reeds_shepp_words_drive_to_the_goal_and_beat_dubins(ora, ora_libm):
+    """What pins the Reeds-Shepp solver beyond the known lengths, without any other implementation of it: the word and
+    the five signed lengths it returns, driven by an integrator of this test's own, end on the goal pose to 1e-9; their
+    absolute sum is the distance it reports; and that distance is never longer than the forward-only path of the
+    (reference-pinned) Dubins solver from start to goal, nor than the one from goal to start driven backwards -- both are
+    Reeds-Shepp paths too.  Near and far goals, and goals at the table's 0.35 m radius."""
+    rng = np.random.default_rng(2024)
+    cases = [(1.0, 6.0), (6.0, 30.0), (0.35, 3.0), (1.0, 0.3)]
+    shorter = 0
+    for o in (ora, ora_libm):
+        for rho, reach in cases:
+            for _ in range(1500):
+                a = np.array([rng.uniform(-reach, reach), rng.uniform(-reach, reach), rng.uniform(0, 2 * math.pi)])
+                b = np.array([rng.uniform(-reach, reach), rng.uniform(-reach, reach), rng.uniform(0, 2 * math.pi)])
+                ty, ln = o.rs_path(rho, a, b)
+                assert 0 <= ty < 18
+                word = RS_WORDS[ty]
+                assert all(ln[k] == 0 for k in range(len(word), 5))
+                dist = o.rs_distance(rho, a, b)
+                assert abs(rho * np.abs(ln).sum() - dist) <= 1e-9 * max(1.0, dist)
+                # the goal in the start's frame, in units of the turning radius
+                dx, dy = b[0] - a[0], b[1] - a[1]
+                c, s_ = math.cos(a[2]), math.sin(a[2])
+                gx, gy, gth = (c * dx + s_ * dy) / rho, (-s_ * dx + c * dy) / rho, b[2] - a[2]
+                x, y, th = _drive(word, ln)
+                assert math.hypot(x - gx, y - gy) <= 1e-9 * max(1.0, abs(gx) + abs(gy)), (rho, a, b, ty, ln)
+                assert abs(math.remainder(th - gth, 2 * math.pi)) <= 1e-9, (rho, a, b, ty, ln)
+                for q0, q1 in ((a, b), (b, a)):
+                    rc, d = o.dubins(q0, q1, rho)
+                    if rc == 0:
+                        assert dist <= float(d[4]) * (1 + 1e-5) + 1e-5, (rho, a, b, dist, d)
+                        shorter += dist < float(d[4]) * (1 - 1e-3)
+    assert shorter > 1000  # (reversing pays on most random pairs: the comparison is not vacuous)
+
+
 def test_rs_table_checksum(ora):
     """Sum of the 131 327 Reeds-Shepp costs of the 60x30, position_resolution 1, rho 0.35 table
     (loops of src/lookup_table.cpp:182-224; x = y = 0 skipped) against the figure recorded from
