@@ -142,6 +142,33 @@ def test_reeds_shepp_words_drive_to_the_goal_and_beat_dubins(ora, ora_libm):
     assert shorter > 1000  # (reversing pays on most random pairs: the comparison is not vacuous)
 
 
+def test_reeds_shepp_distance_is_a_metric(ora):
+    """The shortest-path length is a metric: a distance the solver reports too long (a word family that is missing or
+    wrongly rejected) shows as a broken triangle inequality through some third pose, and a path's length is the sum over
+    its pieces: the distances from the start to a pose on the sampled path and from there to the goal add up (with the
+    rare exception noted below)."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for reach in (1.5, 4.0):
+        P = np.column_stack([rng.uniform(-reach, reach, 900), rng.uniform(-reach, reach, 900), rng.uniform(0, 2 * math.pi, 900)])
+        for _ in range(20000):
+            i, j, k = rng.integers(0, len(P), 3)
+            ab, bc, ac = ora.rs_distance(1.0, P[i], P[j]), ora.rs_distance(1.0, P[j], P[k]), ora.rs_distance(1.0, P[i], P[k])
+            worst = max(worst, ac - ab - bc)
+            assert ac <= ab + bc + 1e-9, (P[i], P[j], P[k], ac, ab, bc)
+    # (a pose inside a straight piece leaves a remainder that starts with an arc of length zero; the closed forms admit an
+    # arc down to -10 eps only, src/ReedsShepp.cpp:48 and :76-79, so rounding makes them miss that remainder now and then and
+    # the next best word is reported: the reference's behaviour, kept.  It must stay rare.)
+    longer = 0
+    for _ in range(1000):
+        a = [rng.uniform(0, 8), rng.uniform(0, 8), rng.uniform(0, 2 * math.pi)]
+        b = [rng.uniform(0, 8), rng.uniform(0, 8), rng.uniform(0, 2 * math.pi)]
+        length, pts = ora.rs_sample(1.0, a, b, 0.25)
+        mid = pts[len(pts) // 2]
+        longer += ora.rs_distance(1.0, a, mid) + ora.rs_distance(1.0, mid, b) > length + 1e-6
+    assert longer <= 5
+
+
 def test_rs_table_checksum(ora):
     """Sum of the 131 327 Reeds-Shepp costs of the 60x30, position_resolution 1, rho 0.35 table
     (loops of src/lookup_table.cpp:182-224; x = y = 0 skipped) against the figure recorded from
